@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE'S OWN hot-path
+functions on seeded synthetic inputs.  Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+The reference's files are imported from where they lie (never copied).  Import shims
+ -- ordinary Python import errors, not refusals:
+  1. a bare package object for ``oisatgmi`` so that ``oisatgmi/__init__.py`` (-> driver -> reader
+     -> netCDF4, absent) is not executed;
+  2. ``scipy.interpolate.interpnd._ndim_coords_from_arrays`` aliased to its scipy-1.15 home;
+  3. a stub ``kneed`` module whose ``KneeLocator`` records (x, y) and returns a FORCED knee --
+     the real package is not installed, so the knee pick itself stays unpinned.
+Only data (inputs, outputs) is written; no reference source text is stored.
+"""
+import dataclasses
+import importlib.util
+import os
+import sys
+import types
+import io
+import contextlib
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+
+# ---- our synthetic generators, loaded under a private name (the name 'oisatgmi' is taken below)
+spec = importlib.util.spec_from_file_location(
+    "oisat_build", os.path.join(ROOT, "oi-sat-gmi_amd", "oisatgmi", "__init__.py"),
+    submodule_search_locations=[os.path.join(ROOT, "oi-sat-gmi_amd", "oisatgmi")])
+oisat_build = importlib.util.module_from_spec(spec)
+sys.modules["oisat_build"] = oisat_build
+spec.loader.exec_module(oisat_build)
+import oisat_build.synthetic as syn          # noqa: E402
+
+# ---- shims + reference import
+pkg = types.ModuleType("oisatgmi")
+pkg.__path__ = [os.path.join(REF, "oisatgmi")]
+sys.modules["oisatgmi"] = pkg
+
+import scipy.interpolate._interpnd as _ip    # noqa: E402
+old = types.ModuleType("scipy.interpolate.interpnd")
+old._ndim_coords_from_arrays = _ip._ndim_coords_from_arrays
+sys.modules["scipy.interpolate.interpnd"] = old
+
+FORCED = {"knee_index": None, "seen": None}
+kneed = types.ModuleType("kneed")
+
+
+class KneeLocator:                                    # recording stub
+    def __init__(self, x, y, **kw):
+        FORCED["seen"] = (np.array(x, dtype=np.float64), np.array(y, dtype=np.float64), dict(kw))
+        i = FORCED["knee_index"]
+        self.knee = None if i is None else x[i]
+
+
+kneed.KneeLocator = KneeLocator
+sys.modules["kneed"] = kneed
+
+sys.dont_write_bytecode = True
+from oisatgmi.optimal_interpolation import OI as REF_OI                 # noqa: E402
+from oisatgmi.averaging import averaging as REF_averaging, error_averager as REF_error_averager  # noqa: E402
+from oisatgmi import interpolator as REF_interp                         # noqa: E402
+from oisatgmi import config as REF_cfg                                  # noqa: E402
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def to_ref(rec):
+    """our record -> the reference's record class, positionally"""
+    if rec is None:
+        return None
+    cls = getattr(REF_cfg, type(rec).__name__)
+    return cls(*[getattr(rec, f.name) for f in dataclasses.fields(rec)])
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrs)
+    print(f"  wrote {name}  ({os.path.getsize(path)/1024:.0f} KiB)")
+
+
+FORCED_IDX = (0, 7, 37, 98)
+
+
+def gen_oi(tag, ny, nx, nobs, seed, full, extra=None):
+    """OI(reg=False), the 99-point curve, OI(reg=True) at forced indices."""
+    extra = extra or {}
+    c = syn.diag_case(ny, nx, nobs, seed, **extra)
+    # a few structural specials: Sa == 0 cell (AK NaN, K = 0), inf obs error, NaN background
+    Xa, Y, Sa, So = c.Xa.copy(), c.Y.copy(), c.Sa.copy(), c.So.copy()
+    obs = np.argwhere(~np.isnan(Y))
+    (i0, j0), (i1, j1), (i2, j2) = obs[0], obs[1], obs[2]
+    Sa[i0, j0] = 0.0
+    So[i1, j1] = np.inf
+    Xa[i2, j2] = np.nan
+    Sa[i2, j2] = np.nan
+    out = {"ny": ny, "nx": nx, "nobs": nobs, "seed": seed}
+    if full:
+        out.update(Xa=Xa, Y=Y, Sa=Sa, So=So)
+    else:
+        out.update(special=np.array([[i0, j0], [i1, j1], [i2, j2]]))
+    stride = 1 if full else 97
+
+    def pack(prefix, res, Yafter):
+        for nm, a in zip(("Xb", "AK", "inc", "err"), res):
+            out[f"{prefix}_{nm}"] = a.ravel()[::stride].copy()
+            out[f"{prefix}_{nm}_nansum"] = np.nansum(a)
+            out[f"{prefix}_{nm}_nnan"] = int(np.isnan(a).sum())
+        out[f"{prefix}_Yafter_nneg"] = int((Yafter < 0).sum())
+
+    Yw = Y.copy()
+    res = quiet(REF_OI, Xa.copy(), Yw, Sa.copy(), So.copy(), regularization_on=False)
+    pack("off", res, Yw)
+    out["Y_clamped"] = Yw.ravel()[::stride].copy()
+    for fi in FORCED_IDX:
+        FORCED["knee_index"] = fi
+        Yw = Y.copy()
+        res = quiet(REF_OI, Xa.copy(), Yw, Sa.copy(), So.copy(), regularization_on=True)
+        pack(f"on{fi}", res, Yw)
+    x, y, kw = FORCED["seen"]
+    out["curve_x"] = x
+    out["curve_y"] = y
+    out["kneed_kwargs"] = np.array(sorted(f"{k}={v}" for k, v in kw.items()))
+    # knee None -> fallback index 0 (optimal_interpolation.py:40-41)
+    FORCED["knee_index"] = None
+    Yw = Y.copy()
+    res = quiet(REF_OI, Xa.copy(), Yw, Sa.copy(), So.copy(), regularization_on=True)
+    pack("onNone", res, Yw)
+    out["stride"] = stride
+    save(f"oi_{tag}.npz", **out)
+
+
+def gen_error_averager():
+    rng = np.random.default_rng(4242)
+    e = rng.uniform(0.01, 1.0, size=(20, 6, 12))
+    e[rng.uniform(size=e.shape) < 0.4] = np.nan
+    e[:, 0, 0] = np.nan                      # all-NaN cell -> 0/0 -> NaN
+    e[3, 1, 1] = np.inf                      # inf is dropped
+    e[:, 2, 2] = np.inf                      # all-inf cell
+    e[:, 3, 3] = np.nan
+    e[5, 3, 3] = 0.25                        # single valid
+    out = REF_error_averager(e.copy())
+    save("error_averager.npz", inp=e, out=out)
+
+
+def gen_averaging():
+    for tag, (ny, nx, k, seed) in {"72x144_k5": (72, 144, 5, 2005), "36x72_k9": (36, 72, 9, 2009)}.items():
+        stack = syn.granule_stack(ny, nx, k, seed)
+
+        class R:
+            pass
+        r = R()
+        r.sat_data = [to_ref(g) for g in stack]
+        res = quiet(REF_averaging, "2019-06-01", "2019-07-01", r)
+        save(f"averaging_{tag}.npz", ny=ny, nx=nx, k=k, seed=seed,
+             sat_vcd=res[0], sat_err=res[1], ctm_vcd=res[2], aux1=res[3], aux2=res[4],
+             avg_ts=np.float64(res[5].timestamp()))
+
+
+def gen_upscaler():
+    rng = np.random.default_rng(3003)
+    gs = 0.25
+    lon = np.arange(-10.0, 10.0 + gs, gs)
+    lat = np.arange(30.0, 45.0 + gs, gs)
+    X, Y = np.meshgrid(lon, lat)
+    Z = 1.0 + np.sin(X / 3.0) * np.cos(Y / 5.0) + 0.01 * rng.normal(size=X.shape)
+    Z[rng.uniform(size=Z.shape) < 0.01] = np.nan
+    Z[0:3, 0:5] = np.nan
+    out = {"X": X, "Y": Y, "Z": Z, "grid_size": gs}
+    cases = {"1x1": (0.25, 0.25), "10x10": (2.5, 2.5), "8x10": (2.0, 2.5), "pass": (0.2, 0.2)}
+    for tag, (dlat, dlon) in cases.items():
+        ctm = syn.regional_ctm_grid(30.0, 45.0, -10.0, 10.0, dlat, dlon)
+        thr = np.sqrt(dlat ** 2 + dlon ** 2)
+        for err in (False, True):
+            ox, oy, oz, need = REF_interp._upscaler(X, Y, Z.copy(), ctm, gs, thr, error=err)
+            k = f"{tag}_{'var' if err else 'mean'}"
+            out[k + "_Z"] = oz
+            out[k + "_need"] = need
+            out[k + "_clat"] = ctm["Latitude"]
+            out[k + "_clon"] = ctm["Longitude"]
+    # kernel tables (interpolator.py:40-46)
+    out["box_3_4"] = REF_interp._boxfilter(3, 4)
+    out["box2_3_4"] = REF_interp._boxfilter2(3, 4)
+    save("upscaler.npz", **out)
+
+
+def gen_interpolator():
+    out = {}
+    g = syn.swath_granule(5005)
+    for f in ("vcd", "amf", "uncertainty", "quality_flag", "latitude_center", "longitude_center"):
+        out["in_" + f] = getattr(g, f)
+    for tag, (dlat, dlon, gs) in {"fine": (0.25, 0.25, 0.25), "coarse": (2.0, 2.5, 0.25)}.items():
+        ctm = syn.regional_ctm_grid(-30.0, 50.0, -25.0, 45.0, dlat, dlon)
+        out[f"{tag}_clat"] = ctm["Latitude"]
+        out[f"{tag}_clon"] = ctm["Longitude"]
+        out[f"{tag}_gs"] = gs
+        for it in (4, 2):
+            r = quiet(REF_interp.interpolator, it, gs, to_ref(g), ctm, 0.75)
+            assert r is not None
+            for f in ("vcd", "amf", "uncertainty", "latitude_center", "longitude_center"):
+                out[f"{tag}_t{it}_{f}"] = np.asarray(getattr(r, f))
+            out[f"{tag}_t{it}_need"] = r.ctm_upscaled_needed
+    # a granule that misses the region -> None (interpolator.py:165-167)
+    ctm = syn.regional_ctm_grid(-80.0, -60.0, 100.0, 140.0, 2.0, 2.5)
+    r = quiet(REF_interp.interpolator, 4, 0.25, to_ref(g), ctm, 0.75)
+    out["miss_is_none"] = r is None
+    save("interpolator.npz", **out)
+
+
+def gen_records():
+    out = {}
+    for nm in ("satellite_amf", "satellite_opt", "satellite_ssmis", "ctm_model"):
+        out[nm] = np.array([f.name for f in dataclasses.fields(getattr(REF_cfg, nm))])
+    save("records.npz", **out)
+
+
+if __name__ == "__main__":
+    print("generating golden vectors from", REF)
+    gen_records()
+    gen_oi("72x144", 72, 144, 1000, 1001, full=True)
+    gen_oi("360x720", 360, 720, 10000, 2001, full=False)
+    gen_oi("o3_72x144", 72, 144, 4000, 5003, full=True,
+           extra=dict(ctm_error=10.0, value_range=(200.0, 500.0), base=250.0, amp=150.0, rel_obs_err=0.04))
+    gen_error_averager()
+    gen_averaging()
+    gen_upscaler()
+    gen_interpolator()
+    print("done")

@@ -1,0 +1,153 @@
+"""The CPU oracle (oracle/oi_oracle.py) against the golden vectors produced by the reference's
+own functions (tests/golden/make_golden.py).  CPU only.  Tolerances: the oracle restates the
+same float64 arithmetic, so 1e-12 relative unless a summation order differs (noted)."""
+import dataclasses
+import datetime
+
+import numpy as np
+import pytest
+
+from oracle import oi_oracle as orc
+from oisatgmi import synthetic as syn
+from oisatgmi import config as cfg
+
+FORCED_IDX = (0, 7, 37, 98)
+
+
+def _specials(c, g):
+    Xa, Y, Sa, So = c.Xa.copy(), c.Y.copy(), c.Sa.copy(), c.So.copy()
+    (i0, j0), (i1, j1), (i2, j2) = g["special"]
+    Sa[i0, j0] = 0.0
+    So[i1, j1] = np.inf
+    Xa[i2, j2] = np.nan
+    Sa[i2, j2] = np.nan
+    return Xa, Y, Sa, So
+
+
+def _oi_inputs(g, tag):
+    if "Xa" in g.files:
+        return g["Xa"].copy(), g["Y"].copy(), g["Sa"].copy(), g["So"].copy()
+    c = syn.diag_case(int(g["ny"]), int(g["nx"]), int(g["nobs"]), int(g["seed"]))
+    return _specials(c, g)
+
+
+def _check_pack(g, prefix, res, Yafter, rtol=1e-12):
+    stride = int(g["stride"])
+    for nm, a in zip(("Xb", "AK", "inc", "err"), res):
+        np.testing.assert_allclose(a.ravel()[::stride], g[f"{prefix}_{nm}"], rtol=rtol, atol=0, equal_nan=True)
+        assert int(np.isnan(a).sum()) == int(g[f"{prefix}_{nm}_nnan"])
+        np.testing.assert_allclose(np.nansum(a), g[f"{prefix}_{nm}_nansum"], rtol=1e-10)
+    assert int((Yafter < 0).sum()) == 0 == int(g[f"{prefix}_Yafter_nneg"])
+
+
+@pytest.mark.parametrize("tag", ["72x144", "360x720", "o3_72x144"])
+def test_oi_against_reference(golden, tag):
+    g = golden(f"oi_{tag}.npz")
+    Xa, Y, Sa, So = _oi_inputs(g, tag)
+    Yw = Y.copy()
+    res = orc.OI(Xa.copy(), Yw, Sa, So, regularization_on=False)
+    _check_pack(g, "off", res[:4], Yw)
+    np.testing.assert_array_equal(Yw.ravel()[::int(g["stride"])], g["Y_clamped"])
+    for fi in FORCED_IDX:
+        Yw = Y.copy()
+        res = orc.OI(Xa.copy(), Yw, Sa, So, regularization_on=True, forced_index=fi)
+        _check_pack(g, f"on{fi}", res[:4], Yw)
+    # the 99-point curve is pinned by the reference; nanmean summation order is numpy's in both
+    np.testing.assert_allclose(np.array(orc.scaling_factors(True)), g["curve_x"], rtol=0, atol=0)
+    np.testing.assert_allclose(res[4], g["curve_y"], rtol=1e-13)
+    Yw = Y.copy()
+    res = orc.OI(Xa.copy(), Yw, Sa, So, regularization_on=True, forced_index=0)
+    _check_pack(g, "onNone", res[:4], Yw)
+    # the reference passes only direction='increasing' to KneeLocator (optimal_interpolation.py:37-38)
+    assert list(g["kneed_kwargs"]) == ["direction=increasing"]
+
+
+def test_error_averager(golden):
+    g = golden("error_averager.npz")
+    out = orc.error_averager(g["inp"])
+    np.testing.assert_allclose(out, g["out"], rtol=1e-13, equal_nan=True)
+    assert np.isnan(out[0, 0]) and np.isnan(out[2, 2])
+    assert out[3, 3] == 0.5
+
+
+class _Reader:
+    pass
+
+
+@pytest.mark.parametrize("tag", ["72x144_k5", "36x72_k9"])
+def test_averaging(golden, tag):
+    g = golden(f"averaging_{tag}.npz")
+    r = _Reader()
+    r.sat_data = syn.granule_stack(int(g["ny"]), int(g["nx"]), int(g["k"]), int(g["seed"]))
+    res = orc.averaging("2019-06-01", "2019-07-01", r, amf_type=cfg.satellite_amf, opt_type=cfg.satellite_opt)
+    for a, nm in zip(res[:5], ("sat_vcd", "sat_err", "ctm_vcd", "aux1", "aux2")):
+        np.testing.assert_allclose(a, g[nm], rtol=1e-13, equal_nan=True)
+    assert abs(res[5].timestamp() - float(g["avg_ts"])) < 1e-3
+
+
+def test_upscaler(golden):
+    g = golden("upscaler.npz")
+    X, Y, Z, gs = g["X"], g["Y"], g["Z"], float(g["grid_size"])
+    for tag in ("1x1", "10x10", "8x10", "pass"):
+        for err in (False, True):
+            k = f"{tag}_{'var' if err else 'mean'}"
+            ctm = {"Latitude": g[k + "_clat"], "Longitude": g[k + "_clon"]}
+            dlat = abs(ctm["Latitude"][0, 0] - ctm["Latitude"][1, 0])
+            dlon = abs(ctm["Longitude"][0, 0] - ctm["Longitude"][0, 1])
+            ox, oy, oz, need = orc.upscaler(X, Y, Z.copy(), ctm, gs, np.sqrt(dlat ** 2 + dlon ** 2), error=err)
+            assert bool(need) == bool(g[k + "_need"])
+            # convolve2d's accumulation order differs from ours: few-ulp slack
+            np.testing.assert_allclose(oz, g[k + "_Z"], rtol=1e-12, equal_nan=True)
+    np.testing.assert_allclose(np.ones((3, 4)) / 12, g["box_3_4"])
+    np.testing.assert_allclose(np.ones((3, 4)) / 144, g["box2_3_4"])
+
+
+def test_interpolator(golden):
+    g = golden("interpolator.npz")
+    s = syn.swath_granule(5005)
+    for f in ("vcd", "amf", "uncertainty", "quality_flag", "latitude_center", "longitude_center"):
+        np.testing.assert_array_equal(getattr(s, f), g["in_" + f])
+    for tag in ("fine", "coarse"):
+        ctm = {"Latitude": g[f"{tag}_clat"], "Longitude": g[f"{tag}_clon"]}
+        for it in (4, 2):
+            r = orc.interpolator(it, float(g[f"{tag}_gs"]), s, ctm, 0.75, record_type=cfg.satellite_amf)
+            assert r is not None and bool(r.ctm_upscaled_needed) == bool(g[f"{tag}_t{it}_need"])
+            for f in ("vcd", "amf", "uncertainty", "latitude_center", "longitude_center"):
+                np.testing.assert_allclose(np.asarray(getattr(r, f)), g[f"{tag}_t{it}_{f}"], rtol=1e-12, equal_nan=True)
+    ctm = syn.regional_ctm_grid(-80.0, -60.0, 100.0, 140.0, 2.0, 2.5)
+    assert orc.interpolator(4, 0.25, s, ctm, 0.75, record_type=cfg.satellite_amf) is None
+    assert bool(g["miss_is_none"])
+
+
+def test_records_match_reference(golden):
+    g = golden("records.npz")
+    for nm in ("satellite_amf", "satellite_opt", "satellite_ssmis", "ctm_model"):
+        ours = [f.name for f in dataclasses.fields(getattr(cfg, nm))]
+        assert ours == list(g[nm])
+
+
+def test_kneedle_properties():
+    """PARITY UNPINNED (kneed absent).  Properties of the published algorithm only."""
+    x = np.arange(0.1, 10, 0.1)
+    y = x / (x + 1.5)                                   # concave increasing, like mean AK vs scale
+    knee, idx = orc.kneedle_knee(x, y)
+    xn = (x - x.min()) / (x.max() - x.min())
+    yn = (y - y.min()) / (y.max() - y.min())
+    assert idx == int(np.argmax(yn - xn)) and knee == x[idx]
+    assert orc.kneedle_knee(x, 2 * x + 1) == (None, None)          # straight line: no knee
+    assert orc.kneedle_knee(x, np.full_like(x, np.nan)) == (None, None)
+
+
+def test_dense_limit_reduces_to_diag():
+    """L -> 0 with H = selection: dense OI == element-wise OI at observed cells, Xa elsewhere."""
+    c = syn.diag_case(18, 36, 120, 77)
+    Yc = c.Y.copy()
+    xb, ak, inc, err, _, _ = orc.OI(c.Xa.copy(), Yc, c.Sa, c.So, regularization_on=False)
+    cells = np.flatnonzero(~np.isnan(Yc.ravel()))
+    r = orc.dense_oi(c.lat, c.lon, c.Xa, c.Sa, c.lat.ravel()[cells], c.lon.ravel()[cells], cells,
+                     Yc.ravel()[cells], c.So.ravel()[cells], L_km=1e-3, want_error=True)
+    np.testing.assert_allclose(r["xa"][cells], xb.ravel()[cells], rtol=1e-12)
+    un = np.setdiff1d(np.arange(c.Xa.size), cells)
+    np.testing.assert_array_equal(r["xa"][un], c.Xa.ravel()[un])
+    np.testing.assert_allclose(r["ak_obs"], ak.ravel()[cells], rtol=1e-10)
+    np.testing.assert_allclose(r["err"][cells], err.ravel()[cells], rtol=1e-10)
