@@ -1,0 +1,176 @@
+/*
+ * oisat.h -- C-ABI of liboisat_hip.so: the MI355X (gfx950) implementation of the
+ * optimal-interpolation hot path of ahsouri/OI-SAT-GMI.
+ *
+ * The reference has NO native/FFI layer: its boundary for this path is the Python call surface
+ * (SURVEY.md section 8(b)).  This header is therefore the C-ABI *underneath* that surface -- what
+ * the Python drop-in (oi-sat-gmi_amd/oisatgmi/) binds with ctypes, and what a maintainer of the
+ * reference would bind from its own modules (stub shown in INTEGRATION.md).  Each entry point
+ * names the reference code it replaces (file:line into the reference tree).
+ *
+ * Conventions
+ *   - plain C: opaque handle, raw pointers, explicit int64 sizes; no torch / numpy types.
+ *   - every function returns 0 on success, a negative OISAT_E* code on failure;
+ *     oisat_last_error() gives the thread-local message.
+ *   - "dev" pointers are HIP device pointers owned by the caller (e.g. torch tensors'
+ *     data_ptr(), or memory from oisat_dmalloc).  Kernels are enqueued on the handle's stream
+ *     (oisat_set_stream) and are asynchronous unless stated; nothing here calls hipMalloc /
+ *     hipFree / hipDeviceSynchronize on a compute path except where a host result is returned.
+ *   - dtype: OISAT_F32 (0) or OISAT_F64 (1) selects the field element type; arithmetic is done
+ *     in that type with the reference's operation order (no fast-math, no FMA contraction), and
+ *     reductions always accumulate in double.
+ */
+#ifndef OISAT_H
+#define OISAT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OISAT_F32 0
+#define OISAT_F64 1
+
+#define OISAT_OK 0
+#define OISAT_EINVAL (-1)   /* bad argument */
+#define OISAT_EHIP (-2)     /* HIP runtime error */
+#define OISAT_ENOMEM (-3)   /* device allocation failed */
+#define OISAT_ENOTPD (-4)   /* Cholesky met a non-positive pivot */
+#define OISAT_ENODEV (-5)   /* no usable gfx950 device */
+
+#define OISAT_MAX_SCALES 128
+
+typedef struct oisat_ctx oisat_ctx;
+
+/* ---- lifetime, errors, memory, stream -------------------------------------------------------- */
+int oisat_init(int device_id, oisat_ctx** out);
+void oisat_shutdown(oisat_ctx* h);
+const char* oisat_last_error(void);
+const char* oisat_version(void);
+int oisat_device_info(oisat_ctx* h, char* name_out, int name_cap, int* cu_count, int64_t* hbm_bytes);
+
+int oisat_set_stream(oisat_ctx* h, void* hip_stream);       /* NULL = the default stream */
+int oisat_sync(oisat_ctx* h);                               /* hipStreamSynchronize(stream) */
+int oisat_dmalloc(oisat_ctx* h, size_t bytes, void** dev_out);
+int oisat_dfree(oisat_ctx* h, void* dev);
+int oisat_h2d(oisat_ctx* h, void* dev_dst, const void* host_src, size_t bytes);   /* async on stream */
+int oisat_d2h(oisat_ctx* h, void* host_dst, const void* dev_src, size_t bytes);   /* synchronises */
+int oisat_memset(oisat_ctx* h, void* dev, int byte_value, size_t bytes);
+
+/* per-kernel HIP-event timing (bench.py roofline leg).  Off by default. */
+int oisat_prof_enable(oisat_ctx* h, int on);
+int oisat_prof_reset(oisat_ctx* h);
+/* synchronises; writes up to cap records; returns the number of distinct kernels (>=0) */
+int oisat_prof_collect(oisat_ctx* h, int cap, char (*names)[64], double* total_ms, int64_t* launches);
+
+/* ---- element-wise OI: optimal_interpolation.py:6-52 ------------------------------------------ */
+/* Regularisation sweep, optimal_interpolation.py:26-33: for each scale s,
+ *   t = Sa*s; K = t*(t+So)^-1; Sb = (1-K)*t; AK = 1 - Sb/t; mean_s = nanmean(AK).
+ * Sa, So: dev, n elements.  scales: HOST doubles (nscales <= OISAT_MAX_SCALES).
+ * mean_out / count_out: HOST arrays of nscales (sum of non-NaN AK / count; count of non-NaN).
+ * Synchronises (returns host values).  Deterministic: fixed launch shape, fixed reduction order. */
+int oisat_oi_curve(oisat_ctx* h, int dtype, const void* Sa, const void* So, int64_t n,
+                   const double* scales, int nscales, double* mean_out, int64_t* count_out);
+
+/* Analysis for ONE scale, optimal_interpolation.py:14 and :46-52:
+ *   Y[Y<0] = 0 (written back in place), K, AK, Sb as above, inc = K*(Y-Xa), Xb = Xa+inc,
+ *   err = sqrt(Sb).  All dev, n elements; any of Xb/AK/inc/err may be NULL to skip it. */
+int oisat_oi_apply(oisat_ctx* h, int dtype, const void* Xa, void* Y_inout, const void* Sa,
+                   const void* So, int64_t n, double scale, void* Xb, void* AK, void* inc, void* err);
+
+/* ---- monthly averaging: averaging.py:11-24 and :97-108 ---------------------------------------- */
+/* out[c] = nanmean_k stack[k][c]  (np.nanmean(axis=0), sequential-k summation like numpy).
+ * stack: dev, k*n contiguous.  inf_to_nan != 0 first maps +/-inf to NaN (averaging.py:92). */
+int oisat_nanmean_stack(oisat_ctx* h, int dtype, const void* stack, int k, int64_t n, int inf_to_nan, void* out);
+
+/* error_averager, averaging.py:11-24: per cell drop NaN/inf, out = sqrt(sum / count^2);
+ * count 0 -> NaN.  square_input != 0: stack holds sigma and is squared first (averaging.py:101). */
+int oisat_error_average(oisat_ctx* h, int dtype, const void* stack, int k, int64_t n, int square_input, void* out);
+
+/* out = (x - offset) / slope  (bias_correct, driver.py:65-106) or x / divisor with offset 0
+ * (O3 unit conversion, driver.py:62-63). */
+int oisat_affine(oisat_ctx* h, int dtype, const void* x, int64_t n, double offset, double slope, void* out);
+
+/* Sa = (Xa*error_ctm/100)^2 and So = err^2, the argument wiring of oisatgmi.oi, driver.py:110-114 */
+int oisat_oi_variances(oisat_ctx* h, int dtype, const void* Xa, const void* sat_err, int64_t n,
+                       double error_ctm, void* Sa_out, void* So_out);
+
+/* ---- regridding: interpolator.py:10-97 --------------------------------------------------------- */
+/* signal.convolve2d(Z, ones(ky,kx)/(kx*ky)^(1|2), boundary='symm', mode='same'),
+ * interpolator.py:40-46,:72-76.  Z, out: dev Ny*Nx row-major.  variance != 0 -> /(kx*ky)^2. */
+int oisat_boxfilter_symm(oisat_ctx* h, int dtype, const void* Z, int64_t Ny, int64_t Nx, int ky, int kx,
+                         int variance, void* out);
+
+/* Bounded-radius exact nearest neighbour (what cKDTree.query + the `dists > 2*threshold` mask
+ * need, interpolator.py:145-150,:78-91,:28-33).  Points/targets: dev double lon/lat arrays.
+ * idx_out: dev int32[T], -1 where no point lies within max_dist (those cells are NaN-masked by
+ * the caller's gather).  Ties resolve to the lowest point index.  Distances are Euclidean in
+ * degree space in double, like the reference.  Synchronises internally (sizes a workspace). */
+int oisat_nn_query(oisat_ctx* h, const double* plon, const double* plat, int64_t P,
+                   const double* tlon, const double* tlat, int64_t T, double max_dist,
+                   int32_t* idx_out, double* dist_out /* may be NULL */);
+
+/* out[f][t] = idx[t] >= 0 ? values[f][idx[t]] : NaN  for nfields stacked fields
+ * (the `Z.ravel()[idx]` + mask of _interpolosis type 2/4, interpolator.py:17-20,:28-33). */
+int oisat_gather_mask(oisat_ctx* h, int dtype, const void* values, int64_t P, int nfields,
+                      const int32_t* idx, int64_t T, void* out);
+
+/* _upscaler fused (interpolator.py:72-91): box-average of the ky*kx window around fine node
+ * idx[t] (symmetric boundary, NaN-poisoning, optional variance kernel), evaluated only at the
+ * fine nodes the model cells pick; idx < 0 -> NaN.  Z: dev nfields*Ny*Nx; out: dev nfields*T. */
+int oisat_boxfilter_pick(oisat_ctx* h, int dtype, const void* Z, int64_t Ny, int64_t Nx, int nfields,
+                         int ky, int kx, int variance, const int32_t* idx, int64_t T, void* out);
+
+/* out = mask_dev ? x*1 : NaN  -- the `field*mask` of interpolator.py:126-128,:163; square != 0
+ * squares first (uncertainty**2*mask, :186).  flag: dev array of dtype, kept if flag > thresh. */
+int oisat_flag_mask(oisat_ctx* h, int dtype, const void* x, const void* flag, int64_t n, double thresh,
+                    int square, void* out);
+
+int oisat_sqrt(oisat_ctx* h, int dtype, const void* x, int64_t n, void* out);      /* interpolator.py:188 */
+
+/* ---- dense Gaussian-B analysis (north-star extension; no reference counterpart) ---------------- */
+/* x_a = x_b + B H^T (H B H^T + R)^-1 (y - H x_b),  B = D^1/2 C D^1/2,
+ * C_ij = exp(-|p_i - p_j|^2 * g),  g = R_earth^2/(2 L^2), p = unit vectors (chord distance).
+ * Reduces to optimal_interpolation.py:27,:49-50 when L -> 0 and H selects grid cells.
+ * All coordinates are double SoA [3][count]; S is float, row-major, leading dimension ld. */
+
+/* S = sig_a sig_b C(a,b) + delta_ab var_a, written for the lower triangle by 64x64 tiles (diagonal
+ * tiles complete) over mp = roundup(m,128) rows; rows/cols m..mp are identity padding.
+ * S must hold mp rows of ld >= mp floats.  oxyz: dev double[3*m]. */
+int oisat_cov_build(oisat_ctx* h, const double* oxyz, const float* osig, const float* ovar, int64_t m,
+                    double g, float* S, int64_t ld);
+
+/* d = y - xb[cell]  (innovation; dev double out). */
+int oisat_innovation(oisat_ctx* h, int dtype, const void* xb, const int64_t* cell, const double* y,
+                     int64_t m, double* d_out);
+
+/* In-place blocked Cholesky S = L L^T (lower; strictly-upper part left untouched), fp32 MFMA
+ * trailing updates.  info_host: 0 ok, j>0 = first non-positive pivot column (1-based). */
+int oisat_potrf(oisat_ctx* h, float* S, int64_t m, int64_t ld, int* info_host);
+
+/* z <- L^-T L^-1 z  (dev double[m], fp32 factor, double accumulation). */
+int oisat_potrs(oisat_ctx* h, const float* L, int64_t m, int64_t ld, double* z_inout);
+
+/* r = d - (C.*sig sig^T + diag(var)) z  evaluated in double on the fly (iterative refinement). */
+int oisat_cov_residual(oisat_ctx* h, const double* oxyz, const float* osig, const float* ovar, int64_t m,
+                       double g, const double* d, const double* z, double* r_out);
+
+/* Solve (H B H^T + R) z = d: potrs + `refine` rounds of double-residual refinement.
+ * resid_host (may be NULL): relative residual norms, refine+1 entries. */
+int oisat_gain_solve(oisat_ctx* h, const float* L, const double* oxyz, const float* osig, const float* ovar,
+                     int64_t m, int64_t ld, double g, const double* d, int refine, double* z_out,
+                     double* resid_host);
+
+/* inc_i = sig_i * sum_a C(i,a) osig_a z_a  (= row i of B H^T times z);  xa = xb + inc.
+ * gxyz: dev double[3*n]; gsig: dev float[n]; z: dev double[m].  xb/xa/inc of `dtype`
+ * (either of xa, inc may be NULL). */
+int oisat_apply_increment(oisat_ctx* h, int dtype, const double* gxyz, const float* gsig, int64_t n,
+                          const double* oxyz, const float* osig, const double* z, int64_t m, double g,
+                          const void* xb, void* xa, void* inc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OISAT_H */

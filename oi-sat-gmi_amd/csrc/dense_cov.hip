@@ -1,0 +1,214 @@
+// Dense Gaussian background-error covariance pieces of the north-star analysis
+//     x_a = x_b + B H^T (H B H^T + R)^-1 (y - H x_b),   B = D^1/2 C D^1/2,
+//     C(p,q) = exp(-g |p-q|^2),  g = R_earth^2 / (2 L^2),  p,q unit vectors on the sphere.
+// The reference has no counterpart (its OI is the L->0, H=I limit: optimal_interpolation.py:27,
+// :49-50).  Chord distance keeps C positive definite on the sphere; |p-q|^2 is formed from
+// coordinate DIFFERENCES (not 2-2p.q) so that fp32 keeps ~1e-7 relative accuracy at small range.
+//
+// Nothing n x m is ever materialised: B H^T (415 GB at n=1,036,800, m=1e5) is generated tile by
+// tile in registers from 3 floats per point, so these kernels are VALU/transcendental-bound
+// (v_exp_f32 is quarter rate), not HBM-bound -- except cov_build, which writes S once (4 m^2 B).
+#include "oisat_common.h"
+
+namespace {
+
+constexpr float kLog2e = 1.4426950408889634f;
+
+// ---- S = sig sig^T .* C + diag(var), lower 64x64 tiles (diagonal tiles complete) ----------------
+__global__ __launch_bounds__(256) void cov_build_kernel(const double* __restrict__ oxyz, const float* __restrict__ osig,
+                                                         const float* __restrict__ ovar, int64_t m, int64_t mp, float g2,
+                                                         float* __restrict__ S, int64_t ld, int ntile) {
+    // triangular tile index -> (ti >= tj)
+    const int64_t b = blockIdx.x;
+    int ti = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
+    while ((int64_t)ti * (ti + 1) / 2 > b) --ti;
+    while ((int64_t)(ti + 1) * (ti + 2) / 2 <= b) ++ti;
+    const int tj = (int)(b - (int64_t)ti * (ti + 1) / 2);
+    __shared__ float4 pa[64], pb[64];            // x, y, z, sig
+    const int t = threadIdx.x;
+    if (t < 128) {
+        const int64_t row = (t < 64 ? (int64_t)ti * 64 + t : (int64_t)tj * 64 + (t - 64));
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < m) v = make_float4((float)oxyz[row], (float)oxyz[m + row], (float)oxyz[2 * m + row], osig[row]);
+        if (t < 64) pa[t] = v; else pb[t - 64] = v;
+    }
+    __syncthreads();
+    const int cx = (t & 15) * 4;                 // 4 consecutive columns -> one 16-byte store
+    const int ry = t >> 4;                       // rows ry, ry+16, ry+32, ry+48
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int r = ry + rr * 16;
+        const int64_t grow = (int64_t)ti * 64 + r;
+        if (grow >= mp) continue;
+        const float4 a = pa[r];
+        float o[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 q = pb[cx + c];
+            const int64_t gcol = (int64_t)tj * 64 + cx + c;
+            const float dx = a.x - q.x, dy = a.y - q.y, dz = a.z - q.z;
+            const float d2 = dx * dx + dy * dy + dz * dz;
+            float v = a.w * q.w * __builtin_amdgcn_exp2f(-g2 * d2);
+            if (grow == gcol) v = grow < m ? a.w * a.w + ovar[grow] : 1.0f;     // padding: identity
+            else if (grow >= m || gcol >= m) v = 0.0f;
+            o[c] = v;
+        }
+        *reinterpret_cast<float4*>(&S[grow * ld + (int64_t)tj * 64 + cx]) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void innovation_kernel(const T* __restrict__ xb, const int64_t* __restrict__ cell,
+                                                          const double* __restrict__ y, int64_t m, double* __restrict__ d) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; a < m; a += stride) d[a] = y[a] - (double)xb[cell[a]];
+}
+
+// ---- r = d - S z in double, S regenerated on the fly (iterative refinement) ----------------------
+// Block = 64 rows; 256 threads = 64 rows x 4 column phases; fixed-order combine (deterministic).
+__global__ __launch_bounds__(256) void cov_residual_kernel(const double* __restrict__ oxyz, const float* __restrict__ osig,
+                                                            const float* __restrict__ ovar, int64_t m, double g,
+                                                            const double* __restrict__ d, const double* __restrict__ z,
+                                                            double* __restrict__ r) {
+    __shared__ double sx[256], sy[256], sz[256], sw[256];      // chunk of 256 columns: coords and sig*z
+    __shared__ double part[4][64];
+    const int t = threadIdx.x;
+    const int lr = t & 63, ph = t >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 64 + lr;
+    const bool live = row < m;
+    const double ax = live ? oxyz[row] : 0.0, ay = live ? oxyz[m + row] : 0.0, az = live ? oxyz[2 * m + row] : 0.0;
+    double acc = 0.0;
+    for (int64_t c0 = 0; c0 < m; c0 += 256) {
+        const int64_t c = c0 + t;
+        __syncthreads();
+        if (c < m) {
+            sx[t] = oxyz[c]; sy[t] = oxyz[m + c]; sz[t] = oxyz[2 * m + c];
+            sw[t] = (double)osig[c] * z[c];
+        } else {
+            sx[t] = 0.0; sy[t] = 0.0; sz[t] = 0.0; sw[t] = 0.0;
+        }
+        __syncthreads();
+        for (int j = ph * 64; j < ph * 64 + 64; ++j) {
+            const double dx = ax - sx[j], dy = ay - sy[j], dz = az - sz[j];
+            acc += exp(-g * (dx * dx + dy * dy + dz * dz)) * sw[j];
+        }
+    }
+    part[ph][lr] = acc;
+    __syncthreads();
+    if (ph == 0 && live) {
+        const double s = ((part[0][lr] + part[1][lr]) + part[2][lr]) + part[3][lr];
+        r[row] = d[row] - ((double)osig[row] * s + (double)ovar[row] * z[row]);
+    }
+}
+
+// ---- inc_i = sig_i * sum_a C(i,a) w_a, w = osig.*z ; xa = xb + inc --------------------------------------------
+// Thread = CELLS grid cells, block = 256 threads; observations stream through LDS in chunks and
+// are read as wave-uniform (broadcast) float4.  fp32 inside a chunk, double across chunks.
+template <typename T, int CELLS>
+__global__ __launch_bounds__(256) void apply_increment_kernel(const double* __restrict__ gxyz, const float* __restrict__ gsig,
+                                                               int64_t n, const double* __restrict__ oxyz,
+                                                               const float* __restrict__ osig, const double* __restrict__ z,
+                                                               int64_t m, float g2,
+                                                               const T* __restrict__ xb, T* __restrict__ xa, T* __restrict__ inc) {
+    constexpr int CH = 512;
+    __shared__ float4 so[CH];
+    const int t = threadIdx.x;
+    float px[CELLS], py[CELLS], pz[CELLS];
+    double acc[CELLS];
+    int64_t cell[CELLS];
+#pragma unroll
+    for (int q = 0; q < CELLS; ++q) {
+        cell[q] = ((int64_t)blockIdx.x * CELLS + q) * 256 + t;
+        const bool live = cell[q] < n;
+        px[q] = live ? (float)gxyz[cell[q]] : 0.f;
+        py[q] = live ? (float)gxyz[n + cell[q]] : 0.f;
+        pz[q] = live ? (float)gxyz[2 * n + cell[q]] : 0.f;
+        acc[q] = 0.0;
+    }
+    for (int64_t c0 = 0; c0 < m; c0 += CH) {
+        __syncthreads();
+        for (int j = t; j < CH; j += 256) {
+            const int64_t c = c0 + j;
+            so[j] = c < m ? make_float4((float)oxyz[c], (float)oxyz[m + c], (float)oxyz[2 * m + c], (float)((double)osig[c] * z[c]))
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+        float part[CELLS];
+#pragma unroll
+        for (int q = 0; q < CELLS; ++q) part[q] = 0.f;
+#pragma unroll 4
+        for (int j = 0; j < CH; ++j) {
+            const float4 o = so[j];
+#pragma unroll
+            for (int q = 0; q < CELLS; ++q) {
+                const float dx = px[q] - o.x, dy = py[q] - o.y, dz = pz[q] - o.z;
+                part[q] += __builtin_amdgcn_exp2f(-g2 * (dx * dx + dy * dy + dz * dz)) * o.w;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < CELLS; ++q) acc[q] += (double)part[q];
+    }
+#pragma unroll
+    for (int q = 0; q < CELLS; ++q) {
+        if (cell[q] < n) {
+            const double v = (double)gsig[cell[q]] * acc[q];
+            if (inc) inc[cell[q]] = (T)v;
+            if (xa) xa[cell[q]] = (T)((double)xb[cell[q]] + v);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int oisat_cov_build(oisat_ctx* h, const double* oxyz, const float* osig, const float* ovar, int64_t m, double g,
+                               float* S, int64_t ld) {
+    ARG_CHECK(h && oxyz && osig && ovar && S && m > 0 && g >= 0.0);
+    const int64_t mp = cdiv(m, 128) * 128;
+    ARG_CHECK(ld >= mp && (ld % 4) == 0 && ((uintptr_t)S % 16) == 0);
+    const int ntile = (int)(mp / 64);
+    const int64_t nblk = (int64_t)ntile * (ntile + 1) / 2;
+    ARG_CHECK(nblk < (int64_t)INT32_MAX);
+    OISAT_LAUNCH(h, "cov_build", cov_build_kernel, dim3((unsigned)nblk), dim3(256), 0, oxyz, osig, ovar, m, mp,
+                 (float)(g * (double)kLog2e), S, ld, ntile);
+    return OISAT_OK;
+}
+
+extern "C" int oisat_innovation(oisat_ctx* h, int dtype, const void* xb, const int64_t* cell, const double* y, int64_t m,
+                                double* d_out) {
+    ARG_CHECK(h && xb && cell && y && d_out && m > 0);
+    ARG_CHECK(dtype == OISAT_F32 || dtype == OISAT_F64);
+    const int grid = stream_grid(m, 256);
+    if (dtype == OISAT_F32) {
+        OISAT_LAUNCH(h, "innovation", (innovation_kernel<float>), dim3(grid), dim3(256), 0, (const float*)xb, cell, y, m, d_out);
+    } else {
+        OISAT_LAUNCH(h, "innovation", (innovation_kernel<double>), dim3(grid), dim3(256), 0, (const double*)xb, cell, y, m, d_out);
+    }
+    return OISAT_OK;
+}
+
+extern "C" int oisat_cov_residual(oisat_ctx* h, const double* oxyz, const float* osig, const float* ovar, int64_t m, double g,
+                                  const double* d, const double* z, double* r_out) {
+    ARG_CHECK(h && oxyz && osig && ovar && d && z && r_out && m > 0);
+    OISAT_LAUNCH(h, "cov_residual", cov_residual_kernel, dim3((unsigned)cdiv(m, 64)), dim3(256), 0, oxyz, osig, ovar, m, g, d,
+                 z, r_out);
+    return OISAT_OK;
+}
+
+extern "C" int oisat_apply_increment(oisat_ctx* h, int dtype, const double* gxyz, const float* gsig, int64_t n,
+                                     const double* oxyz, const float* osig, const double* z, int64_t m, double g,
+                                     const void* xb, void* xa, void* inc) {
+    ARG_CHECK(h && gxyz && gsig && oxyz && osig && z && n > 0 && m > 0 && (xa || inc));
+    ARG_CHECK(!xa || xb);
+    ARG_CHECK(dtype == OISAT_F32 || dtype == OISAT_F64);
+    constexpr int CELLS = 2;
+    const unsigned grid = (unsigned)cdiv(n, 256 * CELLS);
+    const float g2 = (float)(g * (double)kLog2e);
+    if (dtype == OISAT_F32) {
+        OISAT_LAUNCH(h, "apply_increment", (apply_increment_kernel<float, CELLS>), dim3(grid), dim3(256), 0, gxyz, gsig, n, oxyz,
+                     osig, z, m, g2, (const float*)xb, (float*)xa, (float*)inc);
+    } else {
+        OISAT_LAUNCH(h, "apply_increment", (apply_increment_kernel<double, CELLS>), dim3(grid), dim3(256), 0, gxyz, gsig, n,
+                     oxyz, osig, z, m, g2, (const double*)xb, (double*)xa, (double*)inc);
+    }
+    return OISAT_OK;
+}

@@ -1,0 +1,102 @@
+// Internal to liboisat_hip.so -- not installed.  gfx950 only; 64-wide wavefronts are assumed.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/oisat.h"
+
+constexpr int kWave = 64;
+
+void oisat_set_error(const char* fmt, ...);
+
+struct ProfRec {
+    char name[64];
+    double total_ms = 0.0;
+    int64_t launches = 0;
+};
+
+struct ProfPending {
+    int rec;
+    hipEvent_t a, b;
+};
+
+struct oisat_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int cu_count = 0;
+    size_t hbm_bytes = 0;
+    char name[128] = {0};
+    // profiling
+    bool prof = false;
+    std::vector<ProfRec> recs;
+    std::vector<ProfPending> pending;
+    std::vector<hipEvent_t> free_events;
+    // grow-only device workspaces (never freed/reallocated inside a timed region once warm)
+    void* ws[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t ws_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // pinned host scratch for small synchronous read-backs
+    void* pinned = nullptr;
+    size_t pinned_bytes = 0;
+};
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            oisat_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return OISAT_EHIP;                                                                 \
+        }                                                                                      \
+    } while (0)
+
+#define ARG_CHECK(cond)                                                                        \
+    do {                                                                                       \
+        if (!(cond)) {                                                                         \
+            oisat_set_error("invalid argument: %s (%s:%d)", #cond, __FILE__, __LINE__);        \
+            return OISAT_EINVAL;                                                               \
+        }                                                                                      \
+    } while (0)
+
+// workspace slot `slot` of at least `bytes` (grow-only); returns nullptr + error on failure
+void* oisat_ws(oisat_ctx* h, int slot, size_t bytes);
+void* oisat_pinned(oisat_ctx* h, size_t bytes);
+
+int oisat_prof_begin(oisat_ctx* h, const char* name);   // returns pending index or -1
+void oisat_prof_end(oisat_ctx* h, int pending);
+
+// Launch with optional per-kernel event timing on the handle's stream, then check the launch.
+#define OISAT_LAUNCH(h, NAME, kernel, grid, block, shmem, ...)                                 \
+    do {                                                                                       \
+        int _p = (h)->prof ? oisat_prof_begin((h), NAME) : -1;                                 \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, (h)->stream, __VA_ARGS__);              \
+        if (_p >= 0) oisat_prof_end((h), _p);                                                  \
+        hipError_t _le = hipGetLastError();                                                    \
+        if (_le != hipSuccess) {                                                               \
+            oisat_set_error("launch of %s failed: %s", NAME, hipGetErrorString(_le));          \
+            return OISAT_EHIP;                                                                 \
+        }                                                                                      \
+    } while (0)
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// memory-bound grid sizing: enough blocks to fill 256 CUs x 8, grid-stride the rest
+static inline int stream_grid(int64_t work_items, int per_block) {
+    int64_t g = cdiv(work_items, per_block);
+    if (g < 1) g = 1;
+    if (g > 2048) g = 2048;
+    return (int)g;
+}
+
+template <typename T>
+__device__ __forceinline__ T nan_of();
+template <>
+__device__ __forceinline__ float nan_of<float>() { return __builtin_nanf(""); }
+template <>
+__device__ __forceinline__ double nan_of<double>() { return __builtin_nan(""); }

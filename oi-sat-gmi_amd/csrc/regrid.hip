@@ -1,0 +1,378 @@
+// Regridding primitives: interpolator.py:10-97 of the reference
+//   * box filter  = signal.convolve2d(Z, ones/(kx*ky)^(1|2), boundary='symm', mode='same') (:40-46,:72-76)
+//   * nearest neighbour = cKDTree(points).query(targets) + `dists > 2*threshold -> NaN` (:28-33,:78-91,:145-150)
+//
+// The reference builds a fresh k-d tree over ~1e6 nodes for every field it regrids.  Here the
+// neighbour search is done once per (points, targets) pair on the device with a uniform-cell hash
+// whose cell edge equals the mask radius: only neighbours within `max_dist` can survive the mask,
+// so the 3x3 cell block around a target contains every candidate and the search is exact.  The
+// resulting index vector is reused by every field (one gather kernel for a whole stack of fields).
+// Distances are Euclidean in degree space, in double, exactly like the reference; ties go to the
+// lowest point index (cKDTree's tie order is unspecified).
+#include "oisat_common.h"
+
+namespace {
+
+__device__ __forceinline__ int64_t reflect(int64_t i, int64_t n) {
+    // scipy 'symm': edge-repeating reflection, possibly more than once for windows wider than n
+    while (i < 0 || i >= n) {
+        if (i < 0) i = -i - 1;
+        if (i >= n) i = 2 * n - 1 - i;
+    }
+    return i;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void boxfilter_kernel(const T* __restrict__ Z, int64_t Ny, int64_t Nx, int ky, int kx,
+                                                         T w, T* __restrict__ out) {
+    const int64_t total = Ny * Nx;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += stride) {
+        const int64_t i = p / Nx, j = p % Nx;
+        T acc = T(0);
+        for (int a = 0; a < ky; ++a) {
+            const int64_t ii = reflect(i - ky / 2 + a, Ny);
+            for (int b = 0; b < kx; ++b) {
+                const int64_t jj = reflect(j - kx / 2 + b, Nx);
+                acc += Z[ii * Nx + jj] * w;
+            }
+        }
+        out[p] = acc;
+    }
+}
+
+// G lanes cooperate on one picked node: lanes stride the ky*kx window, then a fixed xor-tree adds
+// the G partials (deterministic).  G in {1,4,16,64}.
+template <typename T, int G>
+__global__ __launch_bounds__(256) void boxfilter_pick_kernel(const T* __restrict__ Z, int64_t Ny, int64_t Nx, int nfields,
+                                                              int ky, int kx, T w, const int32_t* __restrict__ idx, int64_t Tn,
+                                                              T* __restrict__ out) {
+    const int64_t gid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const int sub = threadIdx.x % G;
+    const int64_t total = Tn * nfields;
+    const int64_t gstride = ((int64_t)gridDim.x * blockDim.x) / G;
+    const int win = ky * kx;
+    for (int64_t q0 = 0; q0 < total; q0 += gstride) {        // uniform trip count: shuffles need all lanes
+        const int64_t q = q0 + gid;
+        const bool live = q < total;
+        const int64_t f = live ? q / Tn : 0, t = live ? q % Tn : 0;
+        const int32_t node = live ? idx[t] : -1;
+        T acc = T(0);
+        if (node >= 0) {
+            const int64_t i = node / Nx, j = node % Nx;
+            const T* Zf = Z + f * Ny * Nx;
+            for (int e = sub; e < win; e += G) {
+                const int a = e / kx, b = e % kx;
+                acc += Zf[reflect(i - ky / 2 + a, Ny) * Nx + reflect(j - kx / 2 + b, Nx)] * w;
+            }
+        }
+#pragma unroll
+        for (int m = G / 2; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, kWave);
+        if (live && sub == 0) out[q] = node >= 0 ? acc : nan_of<T>();
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gather_mask_kernel(const T* __restrict__ values, int64_t P, int nfields,
+                                                           const int32_t* __restrict__ idx, int64_t Tn, T* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < Tn; t += stride) {
+        const int32_t s = idx[t];
+        for (int f = 0; f < nfields; ++f) out[(int64_t)f * Tn + t] = s >= 0 ? values[(int64_t)f * P + s] : nan_of<T>();
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void flag_mask_kernel(const T* __restrict__ x, const T* __restrict__ flag, int64_t n, T thresh,
+                                                         bool square, T* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        T v = x[i];
+        if (square) v = v * v;
+        out[i] = flag[i] > thresh ? v * T(1) : v * nan_of<T>();     // x*1.0 or x*NaN, interpolator.py:126-128
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sqrt_kernel(const T* __restrict__ x, int64_t n, T* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = sqrt(x[i]);
+}
+
+// ---- uniform-cell hash nearest neighbour -------------------------------------------------------
+struct HashGrid {
+    double x0, y0, inv_h;
+    int nbx, nby;
+};
+
+__device__ __forceinline__ int cell_of(const HashGrid& g, double x, double y, int& cx, int& cy) {
+    cx = (int)floor((x - g.x0) * g.inv_h);
+    cy = (int)floor((y - g.y0) * g.inv_h);
+    return cy * g.nbx + cx;
+}
+
+__global__ __launch_bounds__(256) void nn_count_kernel(const double* __restrict__ px, const double* __restrict__ py, int64_t P,
+                                                        HashGrid g, unsigned* __restrict__ counts, int32_t* __restrict__ pcell) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += stride) {
+        const double x = px[i], y = py[i];
+        int c = -1;
+        if (x == x && y == y) {
+            int cx, cy;
+            cell_of(g, x, y, cx, cy);
+            cx = cx < 0 ? 0 : (cx >= g.nbx ? g.nbx - 1 : cx);
+            cy = cy < 0 ? 0 : (cy >= g.nby ? g.nby - 1 : cy);
+            c = cy * g.nbx + cx;
+            atomicAdd(&counts[c], 1u);
+        }
+        pcell[i] = c;
+    }
+}
+
+// single-block exclusive scan over ncell counters (ncell is at most a few hundred thousand)
+__global__ __launch_bounds__(1024) void nn_scan_kernel(const unsigned* __restrict__ counts, int64_t ncell,
+                                                        unsigned* __restrict__ start, unsigned* __restrict__ cursor) {
+    __shared__ unsigned part[1024];
+    const int t = threadIdx.x;
+    const int64_t chunk = (ncell + 1023) / 1024;
+    const int64_t b = t * chunk, e = (b + chunk < ncell) ? b + chunk : ncell;
+    unsigned s = 0;
+    for (int64_t i = b; i < e; ++i) s += counts[i];
+    part[t] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        unsigned v = t >= off ? part[t - off] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    unsigned run = t == 0 ? 0u : part[t - 1];
+    for (int64_t i = b; i < e; ++i) {
+        start[i] = run;
+        cursor[i] = run;
+        run += counts[i];
+    }
+    if (t == 1023) start[ncell] = part[1023];
+}
+
+__global__ __launch_bounds__(256) void nn_scatter_kernel(const int32_t* __restrict__ pcell, int64_t P, unsigned* __restrict__ cursor,
+                                                          int32_t* __restrict__ sorted) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += stride) {
+        const int c = pcell[i];
+        if (c >= 0) sorted[atomicAdd(&cursor[c], 1u)] = (int32_t)i;
+    }
+}
+
+__global__ __launch_bounds__(256) void nn_query_kernel(const double* __restrict__ px, const double* __restrict__ py,
+                                                        const double* __restrict__ tx, const double* __restrict__ ty, int64_t Tn,
+                                                        HashGrid g, const unsigned* __restrict__ start,
+                                                        const int32_t* __restrict__ sorted, double max_dist,
+                                                        int32_t* __restrict__ idx_out, double* __restrict__ dist_out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < Tn; t += stride) {
+        const double x = tx[t], y = ty[t];
+        double best = __builtin_inf();
+        int32_t bi = -1;
+        if (x == x && y == y) {
+            int cx, cy;
+            cell_of(g, x, y, cx, cy);
+            for (int yy = cy - 1; yy <= cy + 1; ++yy) {
+                if (yy < 0 || yy >= g.nby) continue;
+                for (int xx = cx - 1; xx <= cx + 1; ++xx) {
+                    if (xx < 0 || xx >= g.nbx) continue;
+                    const int c = yy * g.nbx + xx;
+                    for (unsigned s = start[c]; s < start[c + 1]; ++s) {
+                        const int32_t i = sorted[s];
+                        const double dx = px[i] - x, dy = py[i] - y;
+                        const double d2 = dx * dx + dy * dy;
+                        if (d2 < best || (d2 == best && i < bi)) { best = d2; bi = i; }
+                    }
+                }
+            }
+        }
+        const double d = sqrt(best);
+        const bool keep = bi >= 0 && !(d > max_dist);          // mask is `dists > 2*threshold`
+        idx_out[t] = keep ? bi : -1;
+        if (dist_out) dist_out[t] = keep ? d : __builtin_inf();
+    }
+}
+
+}  // namespace
+
+extern "C" int oisat_boxfilter_symm(oisat_ctx* h, int dtype, const void* Z, int64_t Ny, int64_t Nx, int ky, int kx, int variance,
+                                    void* out) {
+    ARG_CHECK(h && Z && out && Ny > 0 && Nx > 0 && ky > 0 && kx > 0);
+    ARG_CHECK(dtype == OISAT_F32 || dtype == OISAT_F64);
+    const double kk = (double)kx * (double)ky;
+    const double w = variance ? 1.0 / (kk * kk) : 1.0 / kk;
+    const int grid = stream_grid(Ny * Nx, 256);
+    if (dtype == OISAT_F32) {
+        OISAT_LAUNCH(h, "boxfilter_symm", (boxfilter_kernel<float>), dim3(grid), dim3(256), 0, (const float*)Z, Ny, Nx, ky, kx,
+                     (float)w, (float*)out);
+    } else {
+        OISAT_LAUNCH(h, "boxfilter_symm", (boxfilter_kernel<double>), dim3(grid), dim3(256), 0, (const double*)Z, Ny, Nx, ky,
+                     kx, w, (double*)out);
+    }
+    return OISAT_OK;
+}
+
+template <typename T>
+static int pick_impl(oisat_ctx* h, const void* Z, int64_t Ny, int64_t Nx, int nfields, int ky, int kx, double w,
+                     const int32_t* idx, int64_t Tn, void* out) {
+    const int win = ky * kx;
+    const int64_t groups = Tn * nfields;
+    if (win >= 48) {
+        const int grid = stream_grid(groups * 64, 256);
+        OISAT_LAUNCH(h, "boxfilter_pick", (boxfilter_pick_kernel<T, 64>), dim3(grid), dim3(256), 0, (const T*)Z, Ny, Nx, nfields,
+                     ky, kx, (T)w, idx, Tn, (T*)out);
+    } else if (win >= 12) {
+        const int grid = stream_grid(groups * 16, 256);
+        OISAT_LAUNCH(h, "boxfilter_pick", (boxfilter_pick_kernel<T, 16>), dim3(grid), dim3(256), 0, (const T*)Z, Ny, Nx, nfields,
+                     ky, kx, (T)w, idx, Tn, (T*)out);
+    } else if (win >= 3) {
+        const int grid = stream_grid(groups * 4, 256);
+        OISAT_LAUNCH(h, "boxfilter_pick", (boxfilter_pick_kernel<T, 4>), dim3(grid), dim3(256), 0, (const T*)Z, Ny, Nx, nfields,
+                     ky, kx, (T)w, idx, Tn, (T*)out);
+    } else {
+        const int grid = stream_grid(groups, 256);
+        OISAT_LAUNCH(h, "boxfilter_pick", (boxfilter_pick_kernel<T, 1>), dim3(grid), dim3(256), 0, (const T*)Z, Ny, Nx, nfields,
+                     ky, kx, (T)w, idx, Tn, (T*)out);
+    }
+    return OISAT_OK;
+}
+
+extern "C" int oisat_boxfilter_pick(oisat_ctx* h, int dtype, const void* Z, int64_t Ny, int64_t Nx, int nfields, int ky, int kx,
+                                    int variance, const int32_t* idx, int64_t Tn, void* out) {
+    ARG_CHECK(h && Z && out && idx && Ny > 0 && Nx > 0 && ky > 0 && kx > 0 && nfields > 0 && Tn > 0);
+    ARG_CHECK(Ny * Nx < (int64_t)INT32_MAX);
+    ARG_CHECK(dtype == OISAT_F32 || dtype == OISAT_F64);
+    const double kk = (double)kx * (double)ky;
+    const double w = variance ? 1.0 / (kk * kk) : 1.0 / kk;
+    if (dtype == OISAT_F32) return pick_impl<float>(h, Z, Ny, Nx, nfields, ky, kx, w, idx, Tn, out);
+    return pick_impl<double>(h, Z, Ny, Nx, nfields, ky, kx, w, idx, Tn, out);
+}
+
+extern "C" int oisat_gather_mask(oisat_ctx* h, int dtype, const void* values, int64_t P, int nfields, const int32_t* idx,
+                                 int64_t Tn, void* out) {
+    ARG_CHECK(h && values && idx && out && P > 0 && nfields > 0 && Tn > 0);
+    ARG_CHECK(dtype == OISAT_F32 || dtype == OISAT_F64);
+    const int grid = stream_grid(Tn, 256);
+    if (dtype == OISAT_F32) {
+        OISAT_LAUNCH(h, "gather_mask", (gather_mask_kernel<float>), dim3(grid), dim3(256), 0, (const float*)values, P, nfields,
+                     idx, Tn, (float*)out);
+    } else {
+        OISAT_LAUNCH(h, "gather_mask", (gather_mask_kernel<double>), dim3(grid), dim3(256), 0, (const double*)values, P,
+                     nfields, idx, Tn, (double*)out);
+    }
+    return OISAT_OK;
+}
+
+extern "C" int oisat_flag_mask(oisat_ctx* h, int dtype, const void* x, const void* flag, int64_t n, double thresh, int square,
+                               void* out) {
+    ARG_CHECK(h && x && flag && out && n > 0);
+    ARG_CHECK(dtype == OISAT_F32 || dtype == OISAT_F64);
+    const int grid = stream_grid(n, 256);
+    if (dtype == OISAT_F32) {
+        OISAT_LAUNCH(h, "flag_mask", (flag_mask_kernel<float>), dim3(grid), dim3(256), 0, (const float*)x, (const float*)flag, n,
+                     (float)thresh, square != 0, (float*)out);
+    } else {
+        OISAT_LAUNCH(h, "flag_mask", (flag_mask_kernel<double>), dim3(grid), dim3(256), 0, (const double*)x, (const double*)flag,
+                     n, thresh, square != 0, (double*)out);
+    }
+    return OISAT_OK;
+}
+
+extern "C" int oisat_sqrt(oisat_ctx* h, int dtype, const void* x, int64_t n, void* out) {
+    ARG_CHECK(h && x && out && n > 0);
+    ARG_CHECK(dtype == OISAT_F32 || dtype == OISAT_F64);
+    const int grid = stream_grid(n, 256);
+    if (dtype == OISAT_F32) {
+        OISAT_LAUNCH(h, "sqrt", (sqrt_kernel<float>), dim3(grid), dim3(256), 0, (const float*)x, n, (float*)out);
+    } else {
+        OISAT_LAUNCH(h, "sqrt", (sqrt_kernel<double>), dim3(grid), dim3(256), 0, (const double*)x, n, (double*)out);
+    }
+    return OISAT_OK;
+}
+
+// host-side min/max of a device coordinate array (sizes the hash grid)
+__global__ __launch_bounds__(256) void minmax_kernel(const double* __restrict__ x, const double* __restrict__ y, int64_t n,
+                                                      double* __restrict__ out /* [4*gridDim] */) {
+    __shared__ double sm[4][256];
+    double xmin = __builtin_inf(), xmax = -__builtin_inf(), ymin = __builtin_inf(), ymax = -__builtin_inf();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double a = x[i], b = y[i];
+        if (a == a && b == b) {
+            xmin = fmin(xmin, a); xmax = fmax(xmax, a);
+            ymin = fmin(ymin, b); ymax = fmax(ymax, b);
+        }
+    }
+    sm[0][threadIdx.x] = xmin; sm[1][threadIdx.x] = xmax; sm[2][threadIdx.x] = ymin; sm[3][threadIdx.x] = ymax;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            sm[0][threadIdx.x] = fmin(sm[0][threadIdx.x], sm[0][threadIdx.x + s]);
+            sm[1][threadIdx.x] = fmax(sm[1][threadIdx.x], sm[1][threadIdx.x + s]);
+            sm[2][threadIdx.x] = fmin(sm[2][threadIdx.x], sm[2][threadIdx.x + s]);
+            sm[3][threadIdx.x] = fmax(sm[3][threadIdx.x], sm[3][threadIdx.x + s]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        for (int q = 0; q < 4; ++q) out[blockIdx.x * 4 + q] = sm[q][0];
+}
+
+extern "C" int oisat_nn_query(oisat_ctx* h, const double* plon, const double* plat, int64_t P, const double* tlon,
+                              const double* tlat, int64_t Tn, double max_dist, int32_t* idx_out, double* dist_out) {
+    ARG_CHECK(h && plon && plat && tlon && tlat && idx_out);
+    ARG_CHECK(P > 0 && P < (int64_t)INT32_MAX && Tn > 0 && max_dist > 0.0 && std::isfinite(max_dist));
+    // 1. bounding box of the points
+    const int mm_blocks = 64;
+    double* mm_dev = (double*)oisat_ws(h, 1, sizeof(double) * 4 * mm_blocks);
+    double* mm_host = (double*)oisat_pinned(h, sizeof(double) * 4 * mm_blocks);
+    if (!mm_dev || !mm_host) return OISAT_ENOMEM;
+    OISAT_LAUNCH(h, "nn_minmax", minmax_kernel, dim3(mm_blocks), dim3(256), 0, plon, plat, P, mm_dev);
+    HIP_TRY(hipMemcpyAsync(mm_host, mm_dev, sizeof(double) * 4 * mm_blocks, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    double xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+    for (int b = 0; b < mm_blocks; ++b) {
+        xmin = fmin(xmin, mm_host[b * 4 + 0]); xmax = fmax(xmax, mm_host[b * 4 + 1]);
+        ymin = fmin(ymin, mm_host[b * 4 + 2]); ymax = fmax(ymax, mm_host[b * 4 + 3]);
+    }
+    // (no finite point at all -> a 1x1 empty grid below: every target comes back -1 / +inf)
+    // 2. hash grid with cell edge = mask radius (coarsened if that would need too many cells)
+    double cell = max_dist;
+    const double spanx = (xmin <= xmax) ? xmax - xmin : 0.0, spany = (ymin <= ymax) ? ymax - ymin : 0.0;
+    const int64_t max_cells = 4 * 1024 * 1024;
+    while ((floor(spanx / cell) + 1.0) * (floor(spany / cell) + 1.0) > (double)max_cells) cell *= 2.0;
+    HashGrid g;
+    g.x0 = (xmin <= xmax) ? xmin : 0.0;
+    g.y0 = (ymin <= ymax) ? ymin : 0.0;
+    g.inv_h = 1.0 / cell;
+    g.nbx = (int)floor(spanx / cell) + 1;
+    g.nby = (int)floor(spany / cell) + 1;
+    const int64_t ncell = (int64_t)g.nbx * g.nby;
+    // workspace slot 2: counts | start (ncell+1) | cursor | pcell (P) | sorted (P)
+    const size_t o_counts = 0;
+    const size_t o_start = o_counts + sizeof(unsigned) * (ncell + 4);
+    const size_t o_cursor = o_start + sizeof(unsigned) * (ncell + 4);
+    const size_t o_pcell = o_cursor + sizeof(unsigned) * (ncell + 4);
+    const size_t o_sorted = o_pcell + sizeof(int32_t) * (P + 4);
+    const size_t total = o_sorted + sizeof(int32_t) * (P + 4);
+    char* ws = (char*)oisat_ws(h, 2, total);
+    if (!ws) return OISAT_ENOMEM;
+    unsigned* counts = (unsigned*)(ws + o_counts);
+    unsigned* start = (unsigned*)(ws + o_start);
+    unsigned* cursor = (unsigned*)(ws + o_cursor);
+    int32_t* pcell = (int32_t*)(ws + o_pcell);
+    int32_t* sorted = (int32_t*)(ws + o_sorted);
+    HIP_TRY(hipMemsetAsync(counts, 0, sizeof(unsigned) * (ncell + 4), h->stream));
+    OISAT_LAUNCH(h, "nn_count", nn_count_kernel, dim3(stream_grid(P, 256)), dim3(256), 0, plon, plat, P, g, counts, pcell);
+    OISAT_LAUNCH(h, "nn_scan", nn_scan_kernel, dim3(1), dim3(1024), 0, (const unsigned*)counts, ncell, start, cursor);
+    OISAT_LAUNCH(h, "nn_scatter", nn_scatter_kernel, dim3(stream_grid(P, 256)), dim3(256), 0, (const int32_t*)pcell, P, cursor,
+                 sorted);
+    OISAT_LAUNCH(h, "nn_query", nn_query_kernel, dim3(stream_grid(Tn, 256)), dim3(256), 0, plon, plat, tlon, tlat, Tn, g,
+                 (const unsigned*)start, (const int32_t*)sorted, max_dist, idx_out, dist_out);
+    return OISAT_OK;
+}

@@ -1,0 +1,264 @@
+"""ctypes binding of ``liboisat_hip.so`` (C-ABI: ``include/oisat.h``).
+
+There is deliberately NO CPU fallback in this package: if the shared library is missing, was
+not built for this machine, or no gfx950 device is visible, every compute entry point raises
+``OisatUnavailable`` with the reason.  (The float64 NumPy oracle under ``oracle/`` is test
+infrastructure and is never imported from here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+F32, F64 = 0, 1
+MAX_SCALES = 128
+
+_c_ctx = C.c_void_p
+_i64 = C.c_int64
+_ptr = C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/oisat.h one to one (tests check the symbol list)
+SIGNATURES = {
+    "oisat_init": (C.c_int, [C.c_int, C.POINTER(_c_ctx)]),
+    "oisat_shutdown": (None, [_c_ctx]),
+    "oisat_last_error": (C.c_char_p, []),
+    "oisat_version": (C.c_char_p, []),
+    "oisat_device_info": (C.c_int, [_c_ctx, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(_i64)]),
+    "oisat_set_stream": (C.c_int, [_c_ctx, _ptr]),
+    "oisat_sync": (C.c_int, [_c_ctx]),
+    "oisat_dmalloc": (C.c_int, [_c_ctx, C.c_size_t, C.POINTER(_ptr)]),
+    "oisat_dfree": (C.c_int, [_c_ctx, _ptr]),
+    "oisat_h2d": (C.c_int, [_c_ctx, _ptr, _ptr, C.c_size_t]),
+    "oisat_d2h": (C.c_int, [_c_ctx, _ptr, _ptr, C.c_size_t]),
+    "oisat_memset": (C.c_int, [_c_ctx, _ptr, C.c_int, C.c_size_t]),
+    "oisat_prof_enable": (C.c_int, [_c_ctx, C.c_int]),
+    "oisat_prof_reset": (C.c_int, [_c_ctx]),
+    "oisat_prof_collect": (C.c_int, [_c_ctx, C.c_int, _ptr, C.POINTER(C.c_double), C.POINTER(_i64)]),
+    "oisat_oi_curve": (C.c_int, [_c_ctx, C.c_int, _ptr, _ptr, _i64, C.POINTER(C.c_double), C.c_int,
+                                 C.POINTER(C.c_double), C.POINTER(_i64)]),
+    "oisat_oi_apply": (C.c_int, [_c_ctx, C.c_int, _ptr, _ptr, _ptr, _ptr, _i64, C.c_double, _ptr, _ptr, _ptr, _ptr]),
+    "oisat_nanmean_stack": (C.c_int, [_c_ctx, C.c_int, _ptr, C.c_int, _i64, C.c_int, _ptr]),
+    "oisat_error_average": (C.c_int, [_c_ctx, C.c_int, _ptr, C.c_int, _i64, C.c_int, _ptr]),
+    "oisat_affine": (C.c_int, [_c_ctx, C.c_int, _ptr, _i64, C.c_double, C.c_double, _ptr]),
+    "oisat_oi_variances": (C.c_int, [_c_ctx, C.c_int, _ptr, _ptr, _i64, C.c_double, _ptr, _ptr]),
+    "oisat_boxfilter_symm": (C.c_int, [_c_ctx, C.c_int, _ptr, _i64, _i64, C.c_int, C.c_int, C.c_int, _ptr]),
+    "oisat_nn_query": (C.c_int, [_c_ctx, _ptr, _ptr, _i64, _ptr, _ptr, _i64, C.c_double, _ptr, _ptr]),
+    "oisat_gather_mask": (C.c_int, [_c_ctx, C.c_int, _ptr, _i64, C.c_int, _ptr, _i64, _ptr]),
+    "oisat_boxfilter_pick": (C.c_int, [_c_ctx, C.c_int, _ptr, _i64, _i64, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       _ptr, _i64, _ptr]),
+    "oisat_flag_mask": (C.c_int, [_c_ctx, C.c_int, _ptr, _ptr, _i64, C.c_double, C.c_int, _ptr]),
+    "oisat_sqrt": (C.c_int, [_c_ctx, C.c_int, _ptr, _i64, _ptr]),
+    "oisat_cov_build": (C.c_int, [_c_ctx, _ptr, _ptr, _ptr, _i64, C.c_double, _ptr, _i64]),
+    "oisat_innovation": (C.c_int, [_c_ctx, C.c_int, _ptr, _ptr, _ptr, _i64, _ptr]),
+    "oisat_potrf": (C.c_int, [_c_ctx, _ptr, _i64, _i64, C.POINTER(C.c_int)]),
+    "oisat_potrs": (C.c_int, [_c_ctx, _ptr, _i64, _i64, _ptr]),
+    "oisat_cov_residual": (C.c_int, [_c_ctx, _ptr, _ptr, _ptr, _i64, C.c_double, _ptr, _ptr, _ptr]),
+    "oisat_gain_solve": (C.c_int, [_c_ctx, _ptr, _ptr, _ptr, _ptr, _i64, _i64, C.c_double, _ptr, C.c_int, _ptr,
+                                   C.POINTER(C.c_double)]),
+    "oisat_apply_increment": (C.c_int, [_c_ctx, C.c_int, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i64, C.c_double, _ptr,
+                                        _ptr, _ptr]),
+}
+
+
+class OisatError(RuntimeError):
+    """A call into liboisat_hip.so returned an error code."""
+
+
+class OisatUnavailable(RuntimeError):
+    """The HIP backend cannot run here (library missing / no MI355X).  There is no fallback."""
+
+
+def library_path() -> str:
+    env = os.environ.get("OISAT_LIB")
+    if env:
+        return env
+    here = os.path.dirname(os.path.abspath(__file__))
+    return os.path.join(os.path.dirname(here), "lib", "liboisat_hip.so")
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load_library():
+    """dlopen the library and declare every prototype.  Works without a GPU (no compute call)."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        path = library_path()
+        if not os.path.exists(path):
+            raise OisatUnavailable(
+                f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"or `make -C oi-sat-gmi_amd/csrc`.  This package has no CPU fallback.")
+        try:
+            lib = C.CDLL(path)
+        except OSError as e:
+            raise OisatUnavailable(f"cannot load {path}: {e}.  This package has no CPU fallback.") from e
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError here = header/library drift
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def dtype_code(dt) -> int:
+    dt = np.dtype(dt)
+    if dt == np.float32:
+        return F32
+    if dt == np.float64:
+        return F64
+    raise TypeError(f"unsupported field dtype {dt}; float32 or float64 only")
+
+
+def compute_dtype(*arrays) -> np.dtype:
+    """Field dtype policy of the drop-in surface: follow the inputs like NumPy would (any float64
+    or non-float input -> float64, all float32 -> float32).  ``OISAT_DTYPE=f32|f64`` overrides."""
+    env = os.environ.get("OISAT_DTYPE", "").lower()
+    if env in ("f32", "float32"):
+        return np.dtype(np.float32)
+    if env in ("f64", "float64"):
+        return np.dtype(np.float64)
+    for a in arrays:
+        if np.asarray(a).dtype != np.float32:
+            return np.dtype(np.float64)
+    return np.dtype(np.float32)
+
+
+class DeviceBuffer:
+    """A block of HBM owned through the C-ABI (``oisat_dmalloc``/``oisat_dfree``)."""
+
+    __slots__ = ("ctx", "ptr", "nbytes")
+
+    def __init__(self, ctx: "Context", nbytes: int):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        p = _ptr()
+        ctx.check(ctx.lib.oisat_dmalloc(ctx.h, max(self.nbytes, 16), C.byref(p)))
+        self.ptr = p.value
+
+    def free(self):
+        if self.ptr is not None and self.ctx is not None and self.ctx.h is not None:
+            self.ctx.lib.oisat_dfree(self.ctx.h, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def at(self, byte_offset: int) -> int:
+        return self.ptr + int(byte_offset)
+
+
+class Context:
+    """One handle per process and device: ``oisat_init`` + the handle's stream."""
+
+    def __init__(self, device: int):
+        self.lib = load_library()
+        h = _c_ctx()
+        rc = self.lib.oisat_init(int(device), C.byref(h))
+        if rc != 0:
+            msg = self.lib.oisat_last_error().decode()
+            raise OisatUnavailable(f"oisat_init(device={device}) failed: {msg}.  This package has no CPU fallback.")
+        self.h = h
+        self.device = int(device)
+
+    # ---- plumbing
+    def check(self, rc: int):
+        if rc != 0:
+            raise OisatError(f"liboisat_hip error {rc}: {self.lib.oisat_last_error().decode()}")
+
+    def close(self):
+        if self.h is not None:
+            self.lib.oisat_shutdown(self.h)
+            self.h = None
+
+    def set_stream(self, stream_handle: int | None):
+        self.check(self.lib.oisat_set_stream(self.h, stream_handle or None))
+
+    def sync(self):
+        self.check(self.lib.oisat_sync(self.h))
+
+    def alloc(self, nbytes: int) -> DeviceBuffer:
+        return DeviceBuffer(self, nbytes)
+
+    def upload(self, arr: np.ndarray, dtype=None) -> DeviceBuffer:
+        a = np.ascontiguousarray(arr, dtype=dtype)
+        buf = DeviceBuffer(self, a.nbytes)
+        self.check(self.lib.oisat_h2d(self.h, buf.ptr, a.ctypes.data, a.nbytes))
+        self.sync()                      # `a` may be a temporary: finish the copy before it dies
+        return buf
+
+    def upload_into(self, dev_ptr: int, arr: np.ndarray, dtype=None) -> int:
+        a = np.ascontiguousarray(arr, dtype=dtype)
+        self.check(self.lib.oisat_h2d(self.h, dev_ptr, a.ctypes.data, a.nbytes))
+        self.sync()
+        return a.nbytes
+
+    def download(self, dev_ptr: int, shape, dtype) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        self.check(self.lib.oisat_d2h(self.h, out.ctypes.data, dev_ptr, out.nbytes))
+        return out
+
+    def device_info(self):
+        name = C.create_string_buffer(128)
+        cu = C.c_int()
+        hbm = _i64()
+        self.check(self.lib.oisat_device_info(self.h, name, 128, C.byref(cu), C.byref(hbm)))
+        return {"name": name.value.decode(), "cu_count": cu.value, "hbm_bytes": hbm.value}
+
+    # ---- profiling
+    def prof_enable(self, on=True):
+        self.check(self.lib.oisat_prof_enable(self.h, 1 if on else 0))
+
+    def prof_reset(self):
+        self.check(self.lib.oisat_prof_reset(self.h))
+
+    def prof_collect(self):
+        cap = 64
+        names = (C.c_char * 64 * cap)()
+        ms = (C.c_double * cap)()
+        cnt = (_i64 * cap)()
+        n = self.lib.oisat_prof_collect(self.h, cap, C.cast(names, _ptr), ms, cnt)
+        if n < 0:
+            self.check(n)
+        out = {}
+        for i in range(min(n, cap)):
+            out[bytes(names[i]).split(b"\0", 1)[0].decode()] = {"total_ms": ms[i], "launches": cnt[i]}
+        return out
+
+
+_ctx = None
+_ctx_lock = threading.Lock()
+
+
+def default_device() -> int:
+    for var in ("OISAT_DEVICE", "LOCAL_RANK"):
+        v = os.environ.get(var)
+        if v not in (None, ""):
+            return int(v)
+    return 0
+
+
+def context() -> Context:
+    """The process-wide handle (created on first use).  Raises ``OisatUnavailable`` loudly when the
+    HIP backend cannot run -- by design nothing in this package computes on the CPU instead."""
+    global _ctx
+    with _ctx_lock:
+        if _ctx is None:
+            _ctx = Context(default_device())
+        return _ctx
+
+
+def reset_context():
+    global _ctx
+    with _ctx_lock:
+        if _ctx is not None:
+            _ctx.close()
+            _ctx = None

@@ -1,0 +1,172 @@
+"""Dense Gaussian-B optimal interpolation on the MI355X (north-star extension).
+
+    x_a = x_b + B H^T (H B H^T + R)^-1 (y - H x_b)
+    B = s D^1/2 C D^1/2,  D = diag(Sa),  C_ij = exp(-chord_ij^2 R_earth^2 / (2 L^2)),  R = diag(So)
+    H = selection of the grid cell that contains each observation
+
+The reference's ``OI`` (optimal_interpolation.py:6-52) is the L -> 0 limit of this with one
+observation per cell: there C = I and K_ii = s Sa_i / (s Sa_i + So_i) (:27).  There is NO
+reference implementation of the dense form, so its parity is pinned only in that limit; away from
+it the check is the float64 restatement in ``oracle/`` ("parity unpinned").
+
+Pipeline (all in HBM, csrc/dense_cov.hip + csrc/dense_chol.hip):
+``oisat_innovation`` -> ``oisat_cov_build`` (S, fp32) -> ``oisat_potrf`` (MFMA fp32 Cholesky) ->
+``oisat_gain_solve`` (triangular solves + float64-residual refinement) -> ``oisat_apply_increment``
+(B H^T z generated on the fly, never stored).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _hip
+
+EARTH_RADIUS_KM = 6371.0
+NB = 128                      # Cholesky block edge (csrc/dense_chol.hip)
+
+
+def unit_vectors(lat_deg, lon_deg) -> np.ndarray:
+    """(3, n) float64 unit vectors, SoA as the kernels want them."""
+    la = np.deg2rad(np.ravel(np.asarray(lat_deg, dtype=np.float64)))
+    lo = np.deg2rad(np.ravel(np.asarray(lon_deg, dtype=np.float64)))
+    return np.ascontiguousarray(np.stack([np.cos(la) * np.cos(lo), np.cos(la) * np.sin(lo), np.sin(la)]))
+
+
+def decay_constant(L_km: float) -> float:
+    """g in C = exp(-g * chord^2) for a correlation length L (km)."""
+    return 0.5 * (EARTH_RADIUS_KM / float(L_km)) ** 2
+
+
+def regular_grid_cell(lat2, lon2, obs_lat, obs_lon):
+    """Flat index of the grid cell containing each observation, for a regular cell-centred grid."""
+    lat2 = np.asarray(lat2)
+    lon2 = np.asarray(lon2)
+    ny, nx = lat2.shape
+    dlat = (lat2[-1, 0] - lat2[0, 0]) / max(ny - 1, 1)
+    dlon = (lon2[0, -1] - lon2[0, 0]) / max(nx - 1, 1)
+    iy = np.clip(np.rint((np.asarray(obs_lat) - lat2[0, 0]) / dlat).astype(np.int64), 0, ny - 1)
+    ix = np.clip(np.rint((np.asarray(obs_lon) - lon2[0, 0]) / dlon).astype(np.int64), 0, nx - 1)
+    return iy * nx + ix
+
+
+class DenseAnalysis:
+    """Device-resident dense analysis for one grid: upload the grid once, then ``load_obs`` /
+    ``run`` per month.  Buffers are sized at ``max_obs`` so nothing is allocated per analysis."""
+
+    def __init__(self, grid_lat, grid_lon, max_obs: int, dtype=np.float32, ctx=None):
+        self.ctx = ctx or _hip.context()
+        self.dt = np.dtype(dtype)
+        self.code = _hip.dtype_code(self.dt)
+        self.shape = np.shape(grid_lat)
+        self.n = int(np.size(grid_lat))
+        self.max_obs = int(max_obs)
+        self.mp_max = -(-self.max_obs // NB) * NB
+        c = self.ctx
+        self.gxyz = c.upload(unit_vectors(grid_lat, grid_lon))
+        item = self.dt.itemsize
+        self.fields = c.alloc(3 * self.n * item)            # xb | xa | inc
+        self.gsig = c.alloc(self.n * 4)
+        m = self.max_obs
+        self.oxyz = c.alloc(3 * m * 8)
+        self.osig = c.alloc(m * 4)
+        self.ovar = c.alloc(m * 4)
+        self.ocell = c.alloc(m * 8)
+        self.oy = c.alloc(m * 8)
+        self.d = c.alloc(m * 8)
+        self.z = c.alloc(m * 8)
+        self.S = c.alloc(self.mp_max * self.mp_max * 4)
+        self.m = 0
+
+    # ---- inputs
+    def load_background(self, Xa, Sa, scale=1.0):
+        c = self.ctx
+        c.upload_into(self.fields.at(0), np.ravel(Xa), dtype=self.dt)
+        sig = np.sqrt(float(scale) * np.ravel(np.asarray(Sa, dtype=np.float64)))
+        self._gsig_host = sig
+        c.upload_into(self.gsig.ptr, sig, dtype=np.float32)
+
+    def load_obs(self, obs_lat, obs_lon, obs_cell, obs_y, obs_var):
+        m = int(np.size(obs_y))
+        if m < 1 or m > self.max_obs:
+            raise ValueError(f"{m} observations; this plan was sized for 1..{self.max_obs}")
+        c = self.ctx
+        self.m = m
+        self.mp = -(-m // NB) * NB
+        cell = np.ascontiguousarray(obs_cell, dtype=np.int64)
+        c.upload_into(self.oxyz.ptr, unit_vectors(obs_lat, obs_lon))
+        c.upload_into(self.osig.ptr, self._gsig_host[cell], dtype=np.float32)
+        c.upload_into(self.ovar.ptr, np.ravel(obs_var), dtype=np.float32)
+        c.upload_into(self.ocell.ptr, cell)
+        c.upload_into(self.oy.ptr, np.ravel(obs_y), dtype=np.float64)
+
+    # ---- the hot path: everything below runs on the device, enqueued on the handle's stream
+    def run(self, L_km: float, refine: int = 2, check_pd: bool = False, want_resid: bool = False):
+        c, lib, h = self.ctx, self.ctx.lib, self.ctx.h
+        m, ld = self.m, self.mp
+        g = decay_constant(L_km)
+        item = self.dt.itemsize
+        xb, xa, inc = (self.fields.at(i * self.n * item) for i in range(3))
+        c.check(lib.oisat_innovation(h, self.code, xb, self.ocell.ptr, self.oy.ptr, m, self.d.ptr))
+        c.check(lib.oisat_cov_build(h, self.oxyz.ptr, self.osig.ptr, self.ovar.ptr, m, g, self.S.ptr, ld))
+        info = C.c_int(0)
+        c.check(lib.oisat_potrf(h, self.S.ptr, m, ld, C.byref(info) if check_pd else None))
+        resid = (C.c_double * (refine + 1))() if want_resid else None
+        c.check(lib.oisat_gain_solve(h, self.S.ptr, self.oxyz.ptr, self.osig.ptr, self.ovar.ptr, m, ld, g, self.d.ptr,
+                                     int(refine), self.z.ptr, resid))
+        c.check(lib.oisat_apply_increment(h, self.code, self.gxyz.ptr, self.gsig.ptr, self.n, self.oxyz.ptr,
+                                          self.osig.ptr, self.z.ptr, m, g, xb, xa, inc))
+        return list(resid) if want_resid else None
+
+    # ---- outputs
+    def download(self):
+        out = self.ctx.download(self.fields.at(self.n * self.dt.itemsize), (2,) + tuple(self.shape), self.dt)
+        return out[0], out[1]
+
+    def download_z(self):
+        return self.ctx.download(self.z.ptr, (self.m,), np.float64)
+
+    def download_S(self):
+        return self.ctx.download(self.S.ptr, (self.mp, self.mp), np.float32)
+
+    @staticmethod
+    def flops(m: int) -> float:
+        """Algorithmic flops of the gain solve as BASELINE.md counts them: m^3/3 + 2 m^2."""
+        return m ** 3 / 3.0 + 2.0 * m ** 2
+
+
+def OI_dense(Xa, Y, Sa, So, lat, lon, L_km, scale=1.0, refine=2, obs=None, dtype=None):
+    """Dense-covariance analysis with the reference's gridded argument convention.
+
+    ``Xa, Sa``: (ny, nx) background and its variance; ``Y, So``: (ny, nx) observations and their
+    variance, NaN where unobserved (as ``oisatgmi.oi`` passes them, driver.py:110-111);
+    ``lat, lon``: (ny, nx) cell centres; ``L_km``: correlation length.  ``obs`` (optional) replaces
+    ``Y, So`` by scattered observations: dict(lat, lon, y, var).
+    Returns ``(Xb, increment, info)``; unlike the element-wise ``OI`` every cell is analysed
+    (unobserved cells get the spread increment instead of NaN).
+    """
+    Xa = np.asarray(Xa)
+    if obs is None:
+        Y[Y < 0] = 0.0                                        # same clamp as optimal_interpolation.py:14
+        ok = np.isfinite(np.ravel(Y)) & np.isfinite(np.ravel(So)) & np.isfinite(np.ravel(Xa)) & np.isfinite(np.ravel(Sa))
+        cell = np.flatnonzero(ok)
+        olat, olon = np.ravel(lat)[cell], np.ravel(lon)[cell]
+        oy, ovar = np.ravel(Y)[cell], np.ravel(So)[cell]
+    else:
+        olat, olon = np.ravel(obs["lat"]), np.ravel(obs["lon"])
+        oy = np.where(np.ravel(obs["y"]) < 0, 0.0, np.ravel(obs["y"]))
+        ovar = np.ravel(obs["var"])
+        cell = regular_grid_cell(lat, lon, olat, olon)
+    dt = np.dtype(dtype) if dtype is not None else _hip.compute_dtype(Xa)
+    plan = DenseAnalysis(lat, lon, max_obs=max(int(cell.size), 1), dtype=dt)
+    xa_f = np.where(np.isfinite(Xa), Xa, 0.0)
+    sa_f = np.where(np.isfinite(Sa), Sa, 0.0)
+    plan.load_background(xa_f, sa_f, scale=scale)
+    plan.load_obs(olat, olon, cell, oy, ovar)
+    resid = plan.run(L_km, refine=refine, check_pd=True, want_resid=True)
+    xb, inc = plan.download()
+    bad = ~np.isfinite(Xa)
+    if bad.any():
+        xb = xb.copy()
+        xb[bad] = np.nan
+    return xb, inc, {"nobs": int(cell.size), "residuals": resid, "cells": cell, "z": plan.download_z()}

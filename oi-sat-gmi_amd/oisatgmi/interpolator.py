@@ -1,0 +1,386 @@
+"""Swath -> model-grid regridding on the MI355X.
+
+Drop-in for ``oisatgmi/interpolator.py`` of the reference (``interpolator``, ``_upscaler``,
+``_interpolosis``, ``_boxfilter``, ``_boxfilter2``), nearest-neighbour interpolator types
+(2 and 4).  What changes underneath:
+
+* the reference builds a k-d tree over the ~1e6 fine-grid nodes inside EVERY ``_upscaler`` call
+  and re-queries the swath tree for every field (interpolator.py:78-88, :28-33).  Here the two
+  neighbour searches (swath pixel -> fine node, fine node -> model cell) run once per granule on
+  the device (``oisat_nn_query``) and the resulting index vectors are reused by every field;
+* all 2-D / per-level fields of a granule are masked, gathered, box-filtered and picked as ONE
+  stacked launch each (``oisat_flag_mask`` -> ``oisat_gather_mask`` -> ``oisat_boxfilter_pick``),
+  never leaving HBM in between; the box average is evaluated only at the fine nodes the model
+  cells pick (interpolator.py:72-91 filters the whole fine grid and throws most of it away).
+
+Types 1 (Delaunay linear) and 3 (RBF) are not implemented on the device yet and raise
+``NotImplementedError`` -- there is no silent CPU path.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _hip
+from .config import satellite_amf, satellite_opt
+
+_I32 = np.dtype(np.int32)
+_F64 = np.dtype(np.float64)
+
+
+def _regrid_dtype() -> np.dtype:
+    """The reference promotes every field to float64 on entry (``field*mask`` with a float64 mask,
+    interpolator.py:127,:163; float64 box kernels, :40-46), so the device pipeline runs in float64
+    unless ``OISAT_DTYPE=f32`` asks for the float32 kernels."""
+    return _hip.compute_dtype(np.empty(0, dtype=np.float64))
+
+
+# --------------------------------------------------------------------------------------------
+def _boxfilter(size_kernel_x, size_kernel_y) -> np.ndarray:
+    """Mean kernel (interpolator.py:40-42)."""
+    return np.full((int(size_kernel_x), int(size_kernel_y)), 1.0) / (size_kernel_x * size_kernel_y)
+
+
+def _boxfilter2(size_kernel_x, size_kernel_y) -> np.ndarray:
+    """Variance-of-the-mean kernel, 1/(n^2) (interpolator.py:44-46)."""
+    return np.full((int(size_kernel_x), int(size_kernel_y)), 1.0) / (size_kernel_x * size_kernel_y) ** 2
+
+
+class NNIndex:
+    """Device-resident stand-in for the ``cKDTree`` / ``Delaunay`` objects the reference threads
+    through ``_interpolosis``: the source points live in HBM and ``query`` runs the bounded-radius
+    exact neighbour search of csrc/regrid.hip."""
+
+    def __init__(self, lon, lat):
+        self.ctx = _hip.context()
+        lon = np.ascontiguousarray(np.ravel(lon), dtype=np.float64)
+        lat = np.ascontiguousarray(np.ravel(lat), dtype=np.float64)
+        self.P = lon.size
+        self.buf = self.ctx.alloc(2 * self.P * 8)
+        self.ctx.upload_into(self.buf.at(0), lon)
+        self.ctx.upload_into(self.buf.at(self.P * 8), lat)
+
+    @classmethod
+    def from_any(cls, obj):
+        if isinstance(obj, cls):
+            return obj
+        for attr in ("data", "points"):                     # scipy cKDTree / Delaunay
+            pts = getattr(obj, attr, None)
+            if pts is not None:
+                pts = np.asarray(pts)
+                return cls(pts[:, 0], pts[:, 1])
+        pts = np.asarray(obj)
+        return cls(pts[:, 0], pts[:, 1])
+
+    def query_device(self, tlon, tlat, max_dist, want_dist=False):
+        """-> (DeviceBuffer int32[T] of point indices (-1 = beyond max_dist), dist buffer or None)"""
+        ctx = self.ctx
+        tlon = np.ascontiguousarray(np.ravel(tlon), dtype=np.float64)
+        tlat = np.ascontiguousarray(np.ravel(tlat), dtype=np.float64)
+        T = tlon.size
+        tb = ctx.alloc(2 * T * 8)
+        ctx.upload_into(tb.at(0), tlon)
+        ctx.upload_into(tb.at(T * 8), tlat)
+        idx = ctx.alloc(T * 4)
+        dist = ctx.alloc(T * 8) if want_dist else None
+        ctx.check(ctx.lib.oisat_nn_query(ctx.h, self.buf.at(0), self.buf.at(self.P * 8), self.P, tb.at(0), tb.at(T * 8),
+                                         T, float(max_dist), idx.ptr, dist.ptr if dist else None))
+        ctx.sync()
+        tb.free()
+        return idx, dist
+
+    def query(self, targets, max_dist=np.inf):
+        """``cKDTree.query``-like host result for targets within ``max_dist`` (others: inf, -1)."""
+        t = np.asarray(targets, dtype=np.float64)
+        idx, dist = self.query_device(t[..., 0], t[..., 1], max_dist, want_dist=True)
+        i = self.ctx.download(idx.ptr, t.shape[:-1], _I32)
+        d = self.ctx.download(dist.ptr, t.shape[:-1], _F64)
+        return d, i
+
+
+def _gather(ctx, dt, values_buf, P, nfields, idx_buf, T):
+    out = ctx.alloc(nfields * T * dt.itemsize)
+    ctx.check(ctx.lib.oisat_gather_mask(ctx.h, _hip.dtype_code(dt), values_buf.ptr, P, nfields, idx_buf.ptr, T, out.ptr))
+    return out
+
+
+def _interpolosis(interpol_func, Z: np.ndarray, X: np.ndarray, Y: np.ndarray, interpolator_type: int,
+                  dists: np.ndarray, threshold: float) -> np.ndarray:
+    """One field, host in / host out (interpolator.py:10-37), types 2 and 4."""
+    if interpolator_type in (1, 3):
+        raise NotImplementedError(
+            f"interpolator_type {interpolator_type} is not implemented in the HIP backend (types 2 and 4 are)")
+    if interpolator_type not in (2, 4):
+        raise Exception("other type of interpolation methods has not been implemented yet")
+    ctx = _hip.context()
+    nn = NNIndex.from_any(interpol_func)
+    dt = _hip.compute_dtype(Z)
+    Zb = ctx.upload(np.ravel(Z), dtype=dt)
+    # the mask radius is carried by `dists`; search wide enough to reproduce the unmasked gather
+    idx, _ = nn.query_device(X, Y, max(2.0 * float(threshold), np.nextafter(2.0 * float(threshold), np.inf)))
+    T = int(np.size(X))
+    out = _gather(ctx, dt, Zb, nn.P, 1, idx, T)
+    ZZ = ctx.download(out.ptr, np.shape(X), dt)
+    ZZ[np.asarray(dists) > threshold * 2.0] = np.nan
+    return ZZ
+
+
+class _UpscalePlan:
+    """fine regular grid -> model grid: kernel sizes + which fine node every model cell picks."""
+
+    def __init__(self, X, Y, ctm_models_coordinate, grid_size, threshold):
+        ctm_latitude = ctm_models_coordinate['Latitude']
+        ctm_longitude = ctm_models_coordinate['Longitude']
+        dlon = np.abs(ctm_longitude[0, 0] - ctm_longitude[0, 1])
+        dlat = np.abs(ctm_latitude[0, 0] - ctm_latitude[1, 0])
+        self.ctm_longitude = ctm_longitude
+        self.ctm_latitude = ctm_latitude
+        self.needed = bool((dlon >= grid_size) or (dlat >= grid_size))        # interpolator.py:64
+        self.Ny, self.Nx = np.shape(X)
+        if not self.needed:
+            return
+        kx = np.floor(dlon / grid_size)
+        ky = np.floor(dlat / grid_size)
+        self.kx = 1 if kx == 0 else int(kx)
+        self.ky = 1 if ky == 0 else int(ky)
+        self.out_shape = np.shape(ctm_latitude)
+        self.T = int(np.size(ctm_latitude))
+        nn = NNIndex(X, Y)                                      # every fine node is a candidate (:78-82)
+        self.idx, _ = nn.query_device(ctm_longitude, ctm_latitude, 2.0 * float(threshold))     # :83-91
+        self.ctx = nn.ctx
+
+    def run(self, fine_buf, nfields, dt, variance):
+        """fine_buf: DeviceBuffer with nfields*(Ny*Nx) elements -> DeviceBuffer nfields*T"""
+        out = self.ctx.alloc(nfields * self.T * dt.itemsize)
+        self.ctx.check(self.ctx.lib.oisat_boxfilter_pick(self.ctx.h, _hip.dtype_code(dt), fine_buf.ptr, self.Ny, self.Nx,
+                                                         nfields, self.ky, self.kx, 1 if variance else 0, self.idx.ptr,
+                                                         self.T, out.ptr))
+        return out
+
+
+_plan_cache = {}
+
+
+def _fingerprint(*arrays):
+    key = []
+    for a in arrays:
+        a = np.asarray(a)
+        key.append((a.shape, a.dtype.str, float(a.flat[0]), float(a.flat[-1]), float(a.sum()),
+                    float(a.flat[a.size // 3]), float(a.flat[(2 * a.size) // 3])))
+    return tuple(key)
+
+
+def _upscale_plan(X, Y, ctm_models_coordinate, grid_size, threshold):
+    key = _fingerprint(X, Y, ctm_models_coordinate['Latitude'], ctm_models_coordinate['Longitude']) + (
+        float(grid_size), float(threshold))
+    plan = _plan_cache.get(key)
+    if plan is None:
+        if len(_plan_cache) >= 8:
+            _plan_cache.pop(next(iter(_plan_cache)))
+        plan = _UpscalePlan(X, Y, ctm_models_coordinate, grid_size, threshold)
+        _plan_cache[key] = plan
+    return plan
+
+
+def _upscaler(X: np.ndarray, Y: np.ndarray, Z: np.ndarray, ctm_models_coordinate: dict, grid_size: float,
+              threshold: float, tri=None, error=False):
+    '''
+        upscaler function (interpolator.py:48-97)
+        Input:
+            X [2D]: x coordinates of the input (Z)
+            Y [2D]: y coordinates of the input (Z)
+            Z [2D]: Z values
+            ctm_models_coordinate [dic]: a dictionary containing lat and lon of the model
+            grid_size [float]: the size of grids defined by the user
+            threshold [float]: any points with distance above this will be masked
+    '''
+    plan = _upscale_plan(X, Y, ctm_models_coordinate, grid_size, threshold)
+    if not plan.needed:
+        return X, Y, Z, True
+    ctx = plan.ctx
+    dt = _regrid_dtype()                  # convolve2d with a float64 kernel returns float64
+    Zb = ctx.upload(Z, dtype=dt)
+    out = plan.run(Zb, 1, dt, bool(error))
+    Zc = ctx.download(out.ptr, plan.out_shape, dt)
+    return plan.ctm_longitude, plan.ctm_latitude, Zc, False
+
+
+# --------------------------------------------------------------------------------------------
+class _GranuleRegridder:
+    """Everything ``interpolator()`` needs for one granule, resident in HBM."""
+
+    def __init__(self, sat_data, grid_size, ctm_models_coordinate, flag_thresh):
+        self.ctx = ctx = _hip.context()
+        ctm_latitude = ctm_models_coordinate['Latitude']
+        ctm_longitude = ctm_models_coordinate['Longitude']
+        dlon = np.abs(ctm_longitude[0, 0] - ctm_longitude[0, 1])
+        dlat = np.abs(ctm_latitude[0, 0] - ctm_latitude[1, 0])
+        threshold_ctm = np.sqrt(dlon ** 2 + dlat ** 2)                                   # interpolator.py:121
+        lat_min, lat_max = np.min(ctm_latitude), np.max(ctm_latitude)
+        lon_min, lon_max = np.min(ctm_longitude), np.max(ctm_longitude)
+        lon_grid = np.arange(lon_min, lon_max + grid_size, grid_size)                    # :141-143
+        lat_grid = np.arange(lat_min, lat_max + grid_size, grid_size)
+        self.lons_grid, self.lats_grid = np.meshgrid(lon_grid, lat_grid)
+        self.fine_shape = self.lons_grid.shape
+        self.Tfine = self.lons_grid.size
+        self.P = int(np.size(sat_data.latitude_center))
+        self.swath_shape = np.shape(np.squeeze(sat_data.quality_flag))
+        self.flag_thresh = float(flag_thresh)
+        self.qflag_host = np.squeeze(sat_data.quality_flag)
+        nn = NNIndex(sat_data.longitude_center, sat_data.latitude_center)
+        self.idx_fine, _ = nn.query_device(self.lons_grid, self.lats_grid, 2.0 * float(grid_size))   # :145-150,:16-33
+        self.plan = _upscale_plan(self.lons_grid, self.lats_grid, ctm_models_coordinate, grid_size, threshold_ctm)
+        self._flag_bufs = {}
+
+    def _flag(self, dt):
+        b = self._flag_bufs.get(dt)
+        if b is None:
+            b = self._flag_bufs[dt] = self.ctx.upload(np.ravel(self.qflag_host), dtype=dt)
+        return b
+
+    def regrid(self, fields, error=False):
+        """``fields``: list of swath-shaped arrays.  Returns (X, Y, [Z per field], upscaled_ctm_needed),
+        each Z = _upscaler(.., _interpolosis(tri, field*mask, ..), .., error=error)[2]."""
+        ctx = self.ctx
+        nf = len(fields)
+        dt = _regrid_dtype()
+        if error:                       # `uncertainty**2*mask`: the square happens in the field's own dtype
+            fields = [np.asarray(a) ** 2 for a in fields]
+        code = _hip.dtype_code(dt)
+        item = dt.itemsize
+        raw = ctx.alloc(nf * self.P * item)
+        for f, a in enumerate(fields):
+            a = np.squeeze(np.asarray(a))
+            if a.size != self.P:
+                raise ValueError(f"field {f} has {a.size} elements, swath has {self.P}")
+            ctx.upload_into(raw.at(f * self.P * item), a, dtype=dt)
+        masked = ctx.alloc(nf * self.P * item)
+        flag = self._flag(dt)
+        for f in range(nf):             # field*mask (x*1.0 | x*NaN), interpolator.py:126-128,:163
+            ctx.check(ctx.lib.oisat_flag_mask(ctx.h, code, raw.at(f * self.P * item), flag.ptr, self.P, self.flag_thresh,
+                                              0, masked.at(f * self.P * item)))
+        fine = _gather(ctx, dt, masked, self.P, nf, self.idx_fine, self.Tfine)
+        if self.plan.needed:
+            out = self.plan.run(fine, nf, dt, error)
+            Z = ctx.download(out.ptr, (nf,) + tuple(self.plan.out_shape), dt)
+            X, Y = self.plan.ctm_longitude, self.plan.ctm_latitude
+            need = False
+        else:
+            Z = ctx.download(fine.ptr, (nf,) + tuple(self.fine_shape), dt)
+            X, Y = self.lons_grid, self.lats_grid
+            need = True
+        return X, Y, [Z[f] for f in range(nf)], need
+
+
+def interpolator(interpolator_type: int, grid_size: float, sat_data, ctm_models_coordinate: dict, flag_thresh=0.75):
+    '''
+        The interpolator function (interpolator.py:100-291)
+        Input:
+            interpolator_type [int]: an index specifying the type of interpolator
+                    1 > Bilinear interpolation  (not on the device yet)
+                    2 > Nearest neighbour
+                    3 > RBF (thin_plate_spline) (not on the device yet)
+                    4 > KDtree (fast nearest neighbour)
+            grid_size [float]: the size of grids defined by the user
+            sat_data  [satellite_amf or satellite_opt]: a dataclass for satellite data
+            ctm_models_coordinate [dic]: a dictionary containing lat and lon of the model
+            flag_thresh [float]: the quality flag threshold
+    '''
+    if interpolator_type in (1, 3):
+        raise NotImplementedError(
+            f"interpolator_type {interpolator_type} is not implemented in the HIP backend (types 2 and 4 are)")
+    if interpolator_type not in (2, 4):
+        raise Exception("other type of interpolation methods has not been implemented yet")
+    rg = _GranuleRegridder(sat_data, grid_size, ctm_models_coordinate, flag_thresh)
+    is_amf = isinstance(sat_data, satellite_amf)
+    is_opt = isinstance(sat_data, satellite_opt)
+
+    # ---- one stacked pass for every mean-kernel field of the granule
+    names, fields = ["vcd"], [sat_data.vcd]
+    print('....................... vcd')
+    if is_amf:
+        print('....................... amf')
+        names.append("amf")
+        fields.append(sat_data.amf)
+    print('....................... tropopause')
+    has_trop = np.size(sat_data.tropopause) != 1
+    if has_trop:
+        names.append("tropopause")
+        fields.append(sat_data.tropopause)
+    nz = np.shape(sat_data.pressure_mid)[0]
+    levels = {}                                           # name -> (first index, count)
+
+    def add_levels(name, cube, count):
+        levels[name] = (len(fields), count)
+        for z in range(count):
+            names.append(f"{name}[{z}]")
+            fields.append(np.squeeze(np.asarray(cube)[z]))
+
+    if is_amf and np.size(sat_data.scattering_weights) != 1:
+        print('....................... SWs [' + str(nz) + ' levels]')
+        add_levels("scattering_weights", sat_data.scattering_weights, nz)
+        print('....................... pmids [' + str(nz) + ' levels]')
+        add_levels("pressure_mid", sat_data.pressure_mid, nz)
+    if is_opt:
+        singles = {}
+        for nm, msg in (("aprior_column", "apriori column"), ("surface_pressure", "surface pressure"),
+                        ("apriori_surface", "apriori surface")):
+            if getattr(sat_data, nm).any():
+                print('....................... ' + msg)
+                singles[nm] = len(fields)
+                names.append(nm)
+                fields.append(getattr(sat_data, nm))
+        print('....................... Xcol')
+        singles["x_col"] = len(fields)
+        names.append("x_col")
+        fields.append(sat_data.x_col)
+        if sat_data.sensor == 'MOPITT':
+            add_levels("averaging_kernels", sat_data.averaging_kernels, nz + 1)
+        if sat_data.sensor == 'GOSAT':
+            add_levels("averaging_kernels", sat_data.averaging_kernels, nz)
+            add_levels("pressure_weight", sat_data.pressure_weight, nz)
+        add_levels("pressure_mid", sat_data.pressure_mid, nz)
+        add_levels("apriori_profile", sat_data.apriori_profile, nz)
+
+    upscaled_X, upscaled_Y, Z, upscaled_ctm_needed = rg.regrid(fields)
+    vcd = Z[0]
+    with np.errstate(all="ignore"):
+        if np.isnan(vcd).all():
+            print("the satellite granule doesn't fall into the region - skipping!")
+            return None
+    by_name = dict(zip(names, Z))
+
+    def cube(name):
+        first, count = levels[name]
+        return np.stack(Z[first:first + count]).astype(np.float64, copy=False)
+
+    tropopause = by_name["tropopause"] if has_trop else np.empty((1))
+    latitude_center = upscaled_Y
+    longitude_center = upscaled_X
+    print('....................... error')
+    _, _, (uncertainty,), _ = rg.regrid([sat_data.uncertainty], error=True)       # variance kernel, :185-187
+    uncertainty = np.sqrt(uncertainty)                                           # :188
+
+    if is_amf:
+        if "scattering_weights" in levels:
+            scattering_weights = cube("scattering_weights")
+            pressure_mid = cube("pressure_mid")
+        else:
+            scattering_weights = np.empty((1))
+            pressure_mid = np.zeros((nz, np.shape(upscaled_X)[0], np.shape(upscaled_X)[1]))
+        return satellite_amf(vcd, by_name["amf"], sat_data.time, tropopause, latitude_center, longitude_center, [], [],
+                             uncertainty, [], pressure_mid, scattering_weights, upscaled_ctm_needed, [], [], [], [])
+    if is_opt:
+        missing = [nm for nm in ("aprior_column", "surface_pressure", "apriori_surface") if nm not in singles]
+        if missing:                      # the reference leaves these names unbound and dies at :285-287
+            raise NameError(f"satellite_opt record has all-zero {missing}; the reference cannot rebuild it either")
+        if sat_data.sensor == 'MOPITT':
+            pressure_weights = np.empty((1))
+        elif sat_data.sensor == 'GOSAT':
+            pressure_weights = cube("pressure_weight")
+        else:
+            raise NameError("averaging_kernels are only regridded for sensor 'MOPITT' or 'GOSAT'")
+        return satellite_opt(vcd, sat_data.time, [], tropopause, latitude_center, longitude_center, [], [],
+                             uncertainty, [], cube("pressure_mid"), cube("averaging_kernels"), upscaled_ctm_needed,
+                             [], [], [], by_name["aprior_column"], cube("apriori_profile"), by_name["surface_pressure"],
+                             by_name["apriori_surface"], by_name["x_col"], pressure_weights, sat_data.sensor)
+    raise TypeError("sat_data must be a satellite_amf or satellite_opt record")

@@ -1,0 +1,86 @@
+"""``OI`` -- the element-wise optimal-interpolation analysis, on the MI355X.
+
+Drop-in for ``oisatgmi/optimal_interpolation.py:6-52`` of the reference: same signature, same
+4-tuple ``(Xb, averaging_kernel, increment, sqrt(Sb))``, same in-place clamp of ``Y`` (:14), same
+NaN semantics (unobserved cells come back NaN, ``Sa*reg == 0`` gives AK = NaN), same two prints.
+The arithmetic runs in ``oisat_oi_curve`` / ``oisat_oi_apply`` (csrc/oi_diag.hip); only the
+99-number knee pick happens on the host (``_kneedle.knee_index``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _hip
+from ._kneedle import knee_index
+
+#: what the last ``OI`` call chose -- {'index', 'scale', 'curve', 'knee_found'}
+last_regularization = {}
+
+
+def scaling_factors(regularization_on=True) -> np.ndarray:
+    """The sweep of prior-error scalings, optimal_interpolation.py:15-20."""
+    if regularization_on == True:                       # noqa: E712  (the reference compares with ==)
+        return np.arange(0.1, 10, 0.1)
+    return np.array([1.0])
+
+
+def _curve(ctx, code, dSa, dSo, n, factors):
+    sc = np.ascontiguousarray(factors, dtype=np.float64)
+    mean = np.empty(sc.size, dtype=np.float64)
+    cnt = np.empty(sc.size, dtype=np.int64)
+    ctx.check(ctx.lib.oisat_oi_curve(ctx.h, code, dSa, dSo, n, sc.ctypes.data_as(C.POINTER(C.c_double)), sc.size,
+                                     mean.ctypes.data_as(C.POINTER(C.c_double)),
+                                     cnt.ctypes.data_as(C.POINTER(C.c_int64))))
+    return mean, cnt
+
+
+def OI(Xa: np.ndarray, Y: np.ndarray, Sa: np.ndarray, So: np.ndarray, regularization_on=True, reg_index=None):
+    '''
+    Optimal interpolation between two variables looking at the exact quantity (K = ones):
+            Xb = Xa + Sa K^T (K Sa K^T + So)^-1 (Y - K Xa)
+
+    ``reg_index`` (extension): force the index into the scaling sweep instead of the knee pick.
+    '''
+    print('Optimal interpolation begins...')
+    Y[Y < 0] = 0.0                                       # in place on the caller's array, like the reference
+    ctx = _hip.context()
+    dt = _hip.compute_dtype(Xa, Y, Sa, So)
+    code = _hip.dtype_code(dt)
+    shape = np.shape(Xa)
+    n = int(np.size(Xa))
+    if not (np.shape(Y) == shape and np.shape(Sa) == shape and np.shape(So) == shape):
+        # the reference would broadcast; the fused kernels want one shape
+        Xa, Y2, Sa, So = np.broadcast_arrays(Xa, Y, Sa, So)
+        shape = Xa.shape
+        n = Xa.size
+    else:
+        Y2 = Y
+    item = dt.itemsize
+    pool = ctx.alloc(8 * n * item)                        # Xa | Y | Sa | So | Xb | AK | inc | err
+    p = [pool.at(i * n * item) for i in range(8)]
+    for dst, a in zip(p[:4], (Xa, Y2, Sa, So)):
+        ctx.upload_into(dst, a, dtype=dt)
+
+    factors = scaling_factors(regularization_on)
+    found = False
+    curve = None
+    if regularization_on == True:                         # noqa: E712
+        curve, _ = _curve(ctx, code, p[2], p[3], n, factors)
+        if reg_index is None:
+            k = knee_index(factors, curve)
+            found = k is not None
+            index = 0 if k is None else int(k)            # empty match -> [0], optimal_interpolation.py:40-41
+        else:
+            index = int(reg_index)
+    else:
+        index = 0
+    scale = float(factors[index])
+    print("The regularization factor is " + str(factors[index]))
+    ctx.check(ctx.lib.oisat_oi_apply(ctx.h, code, p[0], p[1], p[2], p[3], n, scale, p[4], p[5], p[6], p[7]))
+    out = ctx.download(p[4], (4,) + tuple(shape), dt)
+    pool.free()
+    last_regularization.clear()
+    last_regularization.update(index=index, scale=scale, curve=curve, knee_found=found)
+    return out[0], out[1], out[2], out[3]
