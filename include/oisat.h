@@ -139,7 +139,7 @@ int oisat_sqrt(oisat_ctx* h, int dtype, const void* x, int64_t n, void* out);   
 /* S = sig_a sig_b C(a,b) + delta_ab var_a, written for the lower triangle by 64x64 tiles (diagonal
  * tiles complete) over mp = roundup(m,128) rows; rows/cols m..mp are identity padding.
  * S must hold mp rows of ld >= mp floats.  oxyz: dev double[3*m]. */
-int oisat_cov_build(oisat_ctx* h, const double* oxyz, const float* osig, const float* ovar, int64_t m,
+int oisat_cov_build(oisat_ctx* h, const double* oxyz, const double* osig, const double* ovar, int64_t m,
                     double g, float* S, int64_t ld);
 
 /* d = y - xb[cell]  (innovation; dev double out). */
@@ -154,20 +154,20 @@ int oisat_potrf(oisat_ctx* h, float* S, int64_t m, int64_t ld, int* info_host);
 int oisat_potrs(oisat_ctx* h, const float* L, int64_t m, int64_t ld, double* z_inout);
 
 /* r = d - (C.*sig sig^T + diag(var)) z  evaluated in double on the fly (iterative refinement). */
-int oisat_cov_residual(oisat_ctx* h, const double* oxyz, const float* osig, const float* ovar, int64_t m,
+int oisat_cov_residual(oisat_ctx* h, const double* oxyz, const double* osig, const double* ovar, int64_t m,
                        double g, const double* d, const double* z, double* r_out);
 
 /* Solve (H B H^T + R) z = d: potrs + `refine` rounds of double-residual refinement.
  * resid_host (may be NULL): relative residual norms, refine+1 entries. */
-int oisat_gain_solve(oisat_ctx* h, const float* L, const double* oxyz, const float* osig, const float* ovar,
+int oisat_gain_solve(oisat_ctx* h, const float* L, const double* oxyz, const double* osig, const double* ovar,
                      int64_t m, int64_t ld, double g, const double* d, int refine, double* z_out,
                      double* resid_host);
 
 /* inc_i = sig_i * sum_a C(i,a) osig_a z_a  (= row i of B H^T times z);  xa = xb + inc.
- * gxyz: dev double[3*n]; gsig: dev float[n]; z: dev double[m].  xb/xa/inc of `dtype`
+ * gxyz: dev double[3*n]; gsig: dev double[n]; z: dev double[m].  xb/xa/inc of `dtype`
  * (either of xa, inc may be NULL). */
-int oisat_apply_increment(oisat_ctx* h, int dtype, const double* gxyz, const float* gsig, int64_t n,
-                          const double* oxyz, const float* osig, const double* z, int64_t m, double g,
+int oisat_apply_increment(oisat_ctx* h, int dtype, const double* gxyz, const double* gsig, int64_t n,
+                          const double* oxyz, const double* osig, const double* z, int64_t m, double g,
                           const void* xb, void* xa, void* inc);
 
 #ifdef __cplusplus

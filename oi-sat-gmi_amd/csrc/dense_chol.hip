@@ -424,10 +424,10 @@ extern "C" int oisat_potrs(oisat_ctx* h, const float* L, int64_t m, int64_t ld, 
     return OISAT_OK;
 }
 
-extern "C" int oisat_cov_residual(oisat_ctx* h, const double* oxyz, const float* osig, const float* ovar, int64_t m, double g,
+extern "C" int oisat_cov_residual(oisat_ctx* h, const double* oxyz, const double* osig, const double* ovar, int64_t m, double g,
                                   const double* d, const double* z, double* r_out);
 
-extern "C" int oisat_gain_solve(oisat_ctx* h, const float* L, const double* oxyz, const float* osig, const float* ovar, int64_t m,
+extern "C" int oisat_gain_solve(oisat_ctx* h, const float* L, const double* oxyz, const double* osig, const double* ovar, int64_t m,
                                 int64_t ld, double g, const double* d, int refine, double* z_out, double* resid_host) {
     ARG_CHECK(h && L && oxyz && osig && ovar && d && z_out && m > 0 && refine >= 0 && refine <= 8);
     ARG_CHECK(g_factor.S == L && g_factor.m == m && g_factor.ld == ld);

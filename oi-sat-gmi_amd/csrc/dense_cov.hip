@@ -15,8 +15,8 @@ namespace {
 constexpr float kLog2e = 1.4426950408889634f;
 
 // ---- S = sig sig^T .* C + diag(var), lower 64x64 tiles (diagonal tiles complete) ----------------
-__global__ __launch_bounds__(256) void cov_build_kernel(const double* __restrict__ oxyz, const float* __restrict__ osig,
-                                                         const float* __restrict__ ovar, int64_t m, int64_t mp, float g2,
+__global__ __launch_bounds__(256) void cov_build_kernel(const double* __restrict__ oxyz, const double* __restrict__ osig,
+                                                         const double* __restrict__ ovar, int64_t m, int64_t mp, float g2,
                                                          float* __restrict__ S, int64_t ld, int ntile) {
     // triangular tile index -> (ti >= tj)
     const int64_t b = blockIdx.x;
@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void cov_build_kernel(const double* __restrict
     if (t < 128) {
         const int64_t row = (t < 64 ? (int64_t)ti * 64 + t : (int64_t)tj * 64 + (t - 64));
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < m) v = make_float4((float)oxyz[row], (float)oxyz[m + row], (float)oxyz[2 * m + row], osig[row]);
+        if (row < m) v = make_float4((float)oxyz[row], (float)oxyz[m + row], (float)oxyz[2 * m + row], (float)osig[row]);
         if (t < 64) pa[t] = v; else pb[t - 64] = v;
     }
     __syncthreads();
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void cov_build_kernel(const double* __restrict
             const float dx = a.x - q.x, dy = a.y - q.y, dz = a.z - q.z;
             const float d2 = dx * dx + dy * dy + dz * dz;
             float v = a.w * q.w * __builtin_amdgcn_exp2f(-g2 * d2);
-            if (grow == gcol) v = grow < m ? a.w * a.w + ovar[grow] : 1.0f;     // padding: identity
+            if (grow == gcol) v = grow < m ? (float)(osig[grow] * osig[grow] + ovar[grow]) : 1.0f;     // padding: identity
             else if (grow >= m || gcol >= m) v = 0.0f;
             o[c] = v;
         }
@@ -66,8 +66,8 @@ __global__ __launch_bounds__(256) void innovation_kernel(const T* __restrict__ x
 
 // ---- r = d - S z in double, S regenerated on the fly (iterative refinement) ----------------------
 // Block = 64 rows; 256 threads = 64 rows x 4 column phases; fixed-order combine (deterministic).
-__global__ __launch_bounds__(256) void cov_residual_kernel(const double* __restrict__ oxyz, const float* __restrict__ osig,
-                                                            const float* __restrict__ ovar, int64_t m, double g,
+__global__ __launch_bounds__(256) void cov_residual_kernel(const double* __restrict__ oxyz, const double* __restrict__ osig,
+                                                            const double* __restrict__ ovar, int64_t m, double g,
                                                             const double* __restrict__ d, const double* __restrict__ z,
                                                             double* __restrict__ r) {
     __shared__ double sx[256], sy[256], sz[256], sw[256];      // chunk of 256 columns: coords and sig*z
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void cov_residual_kernel(const double* __restr
         __syncthreads();
         if (c < m) {
             sx[t] = oxyz[c]; sy[t] = oxyz[m + c]; sz[t] = oxyz[2 * m + c];
-            sw[t] = (double)osig[c] * z[c];
+            sw[t] = osig[c] * z[c];
         } else {
             sx[t] = 0.0; sy[t] = 0.0; sz[t] = 0.0; sw[t] = 0.0;
         }
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void cov_residual_kernel(const double* __restr
     __syncthreads();
     if (ph == 0 && live) {
         const double s = ((part[0][lr] + part[1][lr]) + part[2][lr]) + part[3][lr];
-        r[row] = d[row] - ((double)osig[row] * s + (double)ovar[row] * z[row]);
+        r[row] = d[row] - (osig[row] * s + ovar[row] * z[row]);
     }
 }
 
@@ -105,9 +105,9 @@ __global__ __launch_bounds__(256) void cov_residual_kernel(const double* __restr
 // Thread = CELLS grid cells, block = 256 threads; observations stream through LDS in chunks and
 // are read as wave-uniform (broadcast) float4.  fp32 inside a chunk, double across chunks.
 template <typename T, int CELLS>
-__global__ __launch_bounds__(256) void apply_increment_kernel(const double* __restrict__ gxyz, const float* __restrict__ gsig,
+__global__ __launch_bounds__(256) void apply_increment_kernel(const double* __restrict__ gxyz, const double* __restrict__ gsig,
                                                                int64_t n, const double* __restrict__ oxyz,
-                                                               const float* __restrict__ osig, const double* __restrict__ z,
+                                                               const double* __restrict__ osig, const double* __restrict__ z,
                                                                int64_t m, float g2,
                                                                const T* __restrict__ xb, T* __restrict__ xa, T* __restrict__ inc) {
     constexpr int CH = 512;
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void apply_increment_kernel(const double* __re
         __syncthreads();
         for (int j = t; j < CH; j += 256) {
             const int64_t c = c0 + j;
-            so[j] = c < m ? make_float4((float)oxyz[c], (float)oxyz[m + c], (float)oxyz[2 * m + c], (float)((double)osig[c] * z[c]))
+            so[j] = c < m ? make_float4((float)oxyz[c], (float)oxyz[m + c], (float)oxyz[2 * m + c], (float)(osig[c] * z[c]))
                           : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void apply_increment_kernel(const double* __re
 #pragma unroll
     for (int q = 0; q < CELLS; ++q) {
         if (cell[q] < n) {
-            const double v = (double)gsig[cell[q]] * acc[q];
+            const double v = gsig[cell[q]] * acc[q];
             if (inc) inc[cell[q]] = (T)v;
             if (xa) xa[cell[q]] = (T)((double)xb[cell[q]] + v);
         }
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void apply_increment_kernel(const double* __re
 
 }  // namespace
 
-extern "C" int oisat_cov_build(oisat_ctx* h, const double* oxyz, const float* osig, const float* ovar, int64_t m, double g,
+extern "C" int oisat_cov_build(oisat_ctx* h, const double* oxyz, const double* osig, const double* ovar, int64_t m, double g,
                                float* S, int64_t ld) {
     ARG_CHECK(h && oxyz && osig && ovar && S && m > 0 && g >= 0.0);
     const int64_t mp = cdiv(m, 128) * 128;
@@ -186,7 +186,7 @@ extern "C" int oisat_innovation(oisat_ctx* h, int dtype, const void* xb, const i
     return OISAT_OK;
 }
 
-extern "C" int oisat_cov_residual(oisat_ctx* h, const double* oxyz, const float* osig, const float* ovar, int64_t m, double g,
+extern "C" int oisat_cov_residual(oisat_ctx* h, const double* oxyz, const double* osig, const double* ovar, int64_t m, double g,
                                   const double* d, const double* z, double* r_out) {
     ARG_CHECK(h && oxyz && osig && ovar && d && z && r_out && m > 0);
     OISAT_LAUNCH(h, "cov_residual", cov_residual_kernel, dim3((unsigned)cdiv(m, 64)), dim3(256), 0, oxyz, osig, ovar, m, g, d,
@@ -194,8 +194,8 @@ extern "C" int oisat_cov_residual(oisat_ctx* h, const double* oxyz, const float*
     return OISAT_OK;
 }
 
-extern "C" int oisat_apply_increment(oisat_ctx* h, int dtype, const double* gxyz, const float* gsig, int64_t n,
-                                     const double* oxyz, const float* osig, const double* z, int64_t m, double g,
+extern "C" int oisat_apply_increment(oisat_ctx* h, int dtype, const double* gxyz, const double* gsig, int64_t n,
+                                     const double* oxyz, const double* osig, const double* z, int64_t m, double g,
                                      const void* xb, void* xa, void* inc) {
     ARG_CHECK(h && gxyz && gsig && oxyz && osig && z && n > 0 && m > 0 && (xa || inc));
     ARG_CHECK(!xa || xb);

@@ -66,11 +66,11 @@ class DenseAnalysis:
         self.gxyz = c.upload(unit_vectors(grid_lat, grid_lon))
         item = self.dt.itemsize
         self.fields = c.alloc(3 * self.n * item)            # xb | xa | inc
-        self.gsig = c.alloc(self.n * 4)
+        self.gsig = c.alloc(self.n * 8)
         m = self.max_obs
         self.oxyz = c.alloc(3 * m * 8)
-        self.osig = c.alloc(m * 4)
-        self.ovar = c.alloc(m * 4)
+        self.osig = c.alloc(m * 8)
+        self.ovar = c.alloc(m * 8)
         self.ocell = c.alloc(m * 8)
         self.oy = c.alloc(m * 8)
         self.d = c.alloc(m * 8)
@@ -84,7 +84,7 @@ class DenseAnalysis:
         c.upload_into(self.fields.at(0), np.ravel(Xa), dtype=self.dt)
         sig = np.sqrt(float(scale) * np.ravel(np.asarray(Sa, dtype=np.float64)))
         self._gsig_host = sig
-        c.upload_into(self.gsig.ptr, sig, dtype=np.float32)
+        c.upload_into(self.gsig.ptr, sig, dtype=np.float64)
 
     def load_obs(self, obs_lat, obs_lon, obs_cell, obs_y, obs_var):
         m = int(np.size(obs_y))
@@ -95,8 +95,8 @@ class DenseAnalysis:
         self.mp = -(-m // NB) * NB
         cell = np.ascontiguousarray(obs_cell, dtype=np.int64)
         c.upload_into(self.oxyz.ptr, unit_vectors(obs_lat, obs_lon))
-        c.upload_into(self.osig.ptr, self._gsig_host[cell], dtype=np.float32)
-        c.upload_into(self.ovar.ptr, np.ravel(obs_var), dtype=np.float32)
+        c.upload_into(self.osig.ptr, self._gsig_host[cell], dtype=np.float64)
+        c.upload_into(self.ovar.ptr, np.ravel(obs_var), dtype=np.float64)
         c.upload_into(self.ocell.ptr, cell)
         c.upload_into(self.oy.ptr, np.ravel(obs_y), dtype=np.float64)
 

@@ -332,7 +332,10 @@ def test_dense_analysis_against_oracle(ctx, ny, nx, m, L):
         assert np.abs(inc.ravel() - ref["inc"]).max() <= tol * scale
         # gain solve: refinement drives the float64 residual of (HBH^T+R) z = d down
         assert info["residuals"][-1] < 1e-9 and info["residuals"][-1] < info["residuals"][0]
-        np.testing.assert_allclose(info["z"], ref["z"], rtol=1e-6, atol=1e-8 * np.abs(ref["z"]).max())
+        # float64 fields: z is the float64 solution.  float32 fields: the innovation itself carries
+        # the fp32 rounding of the background (6e-8 |Xa|), amplified by cond(S) ~ 1e2..1e3 in z
+        ztol = 1e-9 if dt == np.float64 else 2e-5
+        assert np.abs(info["z"] - ref["z"]).max() <= ztol * np.abs(ref["z"]).max()
 
 
 def test_dense_pieces_through_the_c_abi(ctx):
@@ -347,8 +350,8 @@ def test_dense_pieces_through_the_c_abi(ctx):
     S_ref = orc.gaussian_corr(po, po, L) * sb[cell][:, None] * sb[cell][None, :]
     S_ref[np.diag_indices(m)] += p.obs_var
     oxyz = ctx.upload(dense.unit_vectors(p.obs_lat, p.obs_lon))
-    osig = ctx.upload(sb[cell], dtype=np.float32)
-    ovar = ctx.upload(p.obs_var, dtype=np.float32)
+    osig = ctx.upload(sb[cell], dtype=np.float64)
+    ovar = ctx.upload(p.obs_var, dtype=np.float64)
     S = ctx.alloc(mp * mp * 4)
     ctx.check(lib.oisat_cov_build(ctx.h, oxyz.ptr, osig.ptr, ovar.ptr, m, g, S.ptr, mp))
     Sh = ctx.download(S.ptr, (mp, mp), np.float32)
@@ -385,7 +388,8 @@ def test_dense_reduces_to_elementwise_oi_in_the_limit(ctx, golden):
     ok = np.isfinite(Y) & np.isfinite(So) & np.isfinite(Xa) & np.isfinite(Sa)
     xb, inc, info = dense.OI_dense(Xa, Y.copy(), Sa, So, lat, lon, L_km=1e-3, refine=1, dtype=np.float64)
     want = g["off_Xb"].reshape(72, 144)
-    np.testing.assert_allclose(xb[ok], want[ok], rtol=1e-6)
+    # increments are formed in fp32 inside apply_increment: tolerance relative to the field scale
+    assert np.abs(xb[ok] - want[ok]).max() <= 1e-6 * np.nanmax(np.abs(want))
     un = ~ok & np.isfinite(Xa)
     np.testing.assert_array_equal(xb[un], Xa[un])                       # no spread when L -> 0
 
@@ -411,7 +415,7 @@ def test_dense_config2_size_properties(ctx):
     S[np.diag_indices_from(S)] += p.obs_var
     import scipy.linalg as sla
     zr = sla.cho_solve(sla.cho_factor(S, lower=True, overwrite_a=True), y - p.Xa.ravel()[cell])
-    np.testing.assert_allclose(z, zr, rtol=1e-6, atol=1e-8 * np.abs(zr).max())
+    assert np.abs(z - zr).max() <= 2e-5 * np.abs(zr).max()            # float32 background -> float32-rounded innovation
     sel = np.random.default_rng(3).choice(p.Xa.size, 4000, replace=False)
     pg = orc.unit_vectors(p.lat.ravel()[sel], p.lon.ravel()[sel])
     inc_ref = sb[sel] * (orc.gaussian_corr(pg, po, L) @ (sb[cell] * zr))
