@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="config2_360x720_1e4obs", choices=sorted(WORKLOADS))
-    ap.add_argument("--refine", type=int, default=2)
+    ap.add_argument("--refine", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()

@@ -146,6 +146,13 @@ int oisat_cov_build(oisat_ctx* h, const double* oxyz, const double* osig, const 
 int oisat_innovation(oisat_ctx* h, int dtype, const void* xb, const int64_t* cell, const double* y,
                      int64_t m, double* d_out);
 
+/* The one O(m^3) kernel of the factorization, exposed for tests and microbenchmarks:
+ * mode 0: C -= A B^T, mode 1: C = A B^T.  C: M x N (ldc), A: M x K (lda), B: N x K (ldb), row-major,
+ * K-contiguous operands; M, N multiples of 128, K of 32; lower != 0 skips tiles above the diagonal
+ * of a diagonal-anchored C.  fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32. */
+int oisat_gemm_nt(oisat_ctx* h, float* C, int64_t ldc, const float* A, int64_t lda, const float* B, int64_t ldb,
+                  int64_t M, int64_t N, int64_t K, int mode, int lower);
+
 /* In-place blocked Cholesky S = L L^T (lower; strictly-upper part left untouched), fp32 MFMA
  * trailing updates.  info_host: 0 ok, j>0 = first non-positive pivot column (1-based). */
 int oisat_potrf(oisat_ctx* h, float* S, int64_t m, int64_t ld, int* info_host);

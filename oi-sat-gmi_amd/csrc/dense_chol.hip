@@ -35,7 +35,7 @@ constexpr int LDSW = 36;         // padded LDS row stride in floats (144 B, 16-B
 struct ChFactor {                // what potrs needs besides L: the inverted diagonal blocks
     const float* S = nullptr;
     int64_t m = 0, mp = 0, ld = 0;
-    float* tinv = nullptr;       // [mp/NB][2][NB][NB]: Tinv row-major, then Tinv^T row-major
+    float* tinv = nullptr;       // [mp/NB][NB][NB]: inverted diagonal blocks, row-major
 };
 static thread_local ChFactor g_factor;   // one factor per host thread (one handle per thread/GPU)
 
@@ -152,58 +152,177 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(float* C, int64_t ldc, 
 }
 
 // ---- diagonal block: Cholesky + inverse of one 128x128 block, one workgroup, all in LDS ----------
-// Left-looking, thread = row: s_ij = a_ij - sum_{c<j} l_ic l_jc.  l_jc is wave-uniform (LDS
-// broadcast), l_ic is the thread's own row with an odd row stride (conflict-free).
-__global__ __launch_bounds__(128) void potrf_diag_kernel(float* __restrict__ S, int64_t ld, int64_t k0, float* __restrict__ tinv,
+// Right-looking at 16-column granularity, 4 waves.  Per block column J:
+//   (1) wave 0 factors the 16x16 diagonal block in registers (lane = row, columns in VGPRs, pivots
+//       broadcast with v_readlane) and inverts it the same way;
+//   (2) panel below:   P_I  = A[I,J] * Dinv_J^T          (v_mfma_f32_16x16x4_f32, 4 per 16x16 block)
+//   (3) trailing:      A[I,K] -= P_I * P_K^T,  J < K <= I
+// then T = L^-1 by doubling (16 -> 32 -> 64 -> 128):  T21 = -T22 * (L21 * T11), both products on
+// MFMA; the intermediate L21*T11 is parked in the unused upper triangle of the L image.
+// LDS: a[128][130] (L), t[128][130] (T), dinv[8][16][17].  Row stride 130 = 2 mod 32 keeps the
+// (row = lane&15, k = lane>>4) MFMA operand reads conflict-free.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int LDA = 130;
+constexpr int DINV_LD = 17;
+constexpr int DINV_SZ = 16 * DINV_LD;
+
+__device__ __forceinline__ float rdlane(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
+__device__ __forceinline__ void diag16_factor_invert(float* a, int j0, float* dinvJ, int* info, int col0, int lane) {
+    const int r = lane & 15;
+    float d[16], rinv[16], x[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) d[c] = a[(j0 + r) * LDA + j0 + c];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        float piv = rdlane(d[k], k);
+        if (!(piv > 0.f)) {                               // non-positive or NaN pivot (wave-uniform)
+            if (lane == 0) atomicCAS(info, 0, col0 + k + 1);
+            piv = 1.f;
+        }
+        float ri = __builtin_amdgcn_rsqf(piv);
+        ri = ri * (1.5f - 0.5f * piv * ri * ri);          // one Newton step: ~0.5 ulp
+        rinv[k] = ri;
+        d[k] = (r == k) ? piv * ri : d[k] * ri;
+#pragma unroll
+        for (int c = k + 1; c < 16; ++c) d[c] -= d[k] * rdlane(d[k], c);
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+        if (lane < 16) a[(j0 + r) * LDA + j0 + c] = (c <= r) ? d[c] : 0.f;
+    // inverse, lane = column r of X = L_D^-1
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+        float v = (rr == r) ? 1.f : 0.f;
+#pragma unroll
+        for (int k = 0; k < rr; ++k) v -= rdlane(d[k], rr) * x[k];
+        x[rr] = (rr >= r) ? v * rinv[rr] : 0.f;
+    }
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr)
+        if (lane < 16) dinvJ[rr * DINV_LD + r] = x[rr];
+}
+
+__global__ __launch_bounds__(256) void potrf_diag_kernel(float* __restrict__ S, int64_t ld, int64_t k0, float* __restrict__ tinv,
                                                           int* __restrict__ info, int block_index) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    constexpr int LD = NB + 1;
-    float* a = sm;                     // [128][129]
-    float* x = sm + NB * LD;           // [128][129]  inverse, stored transposed: x[c][r] = Tinv[r][c]
-    __shared__ float diag_s;
-    const int i = threadIdx.x;
+    float* a = sm;                         // [128][LDA]
+    float* t = sm + NB * LDA;              // [128][LDA]
+    float* dinv = t + NB * LDA;            // [8][16][17]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lr = lane & 15, lg = lane >> 4;
     float* Sb = S + k0 * ld + k0;
-    for (int c = 0; c < NB; ++c) {     // coalesced: thread = column here
-        a[c * LD + i] = (i <= c) ? Sb[(int64_t)c * ld + i] : 0.f;
-    }
-    __syncthreads();
-    for (int j = 0; j < NB; ++j) {
-        float s = 0.f;
-        if (i >= j) {
-            s = a[i * LD + j];
-            for (int c = 0; c < j; ++c) s -= a[i * LD + c] * a[j * LD + c];
-        }
-        if (i == j) {
-            if (!(s > 0.f)) {          // non-positive or NaN pivot
-                atomicCAS(info, 0, (int)(k0 + j + 1));
-                s = 1.f;
-            }
-            diag_s = sqrtf(s);
-        }
-        __syncthreads();
-        if (i == j) a[i * LD + j] = diag_s;
-        else if (i > j) a[i * LD + j] = s / diag_s;
-        __syncthreads();
-    }
-    // inverse: thread = column c of Tinv; x_r = (delta_rc - sum_{k<r} l_rk x_k) / l_rr, r >= c
-    {
-        const int c = i;
-        for (int r = 0; r < NB; ++r) {
-            float v = 0.f;
-            if (r >= c) {
-                v = (r == c) ? 1.f : 0.f;
-                for (int k = c; k < r; ++k) v -= a[r * LD + k] * x[c * LD + k];
-                v /= a[r * LD + r];
-            }
-            x[c * LD + r] = v;
+    {   // 16 independent 16-byte loads per thread, issued together (row = (tid>>5)+8p, 4 columns at (tid&31)*4)
+        float4 v[16];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) v[p] = *reinterpret_cast<const float4*>(Sb + (int64_t)((tid >> 5) + 8 * p) * ld + (tid & 31) * 4);
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const int r = (tid >> 5) + 8 * p, c = (tid & 31) * 4;
+            float* q = a + r * LDA + c;
+            float* z = t + r * LDA + c;
+            q[0] = (c + 0 <= r) ? v[p].x : 0.f; q[1] = (c + 1 <= r) ? v[p].y : 0.f;
+            q[2] = (c + 2 <= r) ? v[p].z : 0.f; q[3] = (c + 3 <= r) ? v[p].w : 0.f;
+            z[0] = 0.f; z[1] = 0.f; z[2] = 0.f; z[3] = 0.f;
         }
     }
     __syncthreads();
-    for (int c = 0; c < NB; ++c) {
-        const float l = a[c * LD + i];                         // row c, column i
-        if (i <= c) Sb[(int64_t)c * ld + i] = l;
-        tinv[(((int64_t)block_index * 2 + 0) * NB + c) * NB + i] = x[i * LD + c];     // Tinv[c][i]
-        tinv[(((int64_t)block_index * 2 + 1) * NB + c) * NB + i] = x[c * LD + i];     // Tinv^T[c][i] = Tinv[i][c]
+    for (int J = 0; J < 8; ++J) {
+        const int j0 = 16 * J;
+        float* dJ = dinv + J * DINV_SZ;
+        if (w == 0) diag16_factor_invert(a, j0, dJ, info, (int)(k0 + j0), lane);
+        __syncthreads();
+        for (int I = J + 1 + w; I < 8; I += 4) {          // panel: P_I = A[I,J] * Dinv^T
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float av = a[(16 * I + lr) * LDA + j0 + 4 * s + lg];
+                const float bv = dJ[lr * DINV_LD + 4 * s + lg];               // B[k][j] = Dinv[j][k]
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[(16 * I + 4 * lg + e) * LDA + j0 + lr] = acc[e];
+        }
+        __syncthreads();
+        const int n = 7 - J, np = n * (n + 1) / 2;        // trailing pairs (I >= K > J)
+        for (int p = w; p < np; p += 4) {
+            int kk = 0, rem = p;
+            while (rem >= n - kk) { rem -= n - kk; ++kk; }
+            const int K = J + 1 + kk, I = K + rem;
+            f32x4 acc;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = a[(16 * I + 4 * lg + e) * LDA + 16 * K + lr];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float av = -a[(16 * I + lr) * LDA + j0 + 4 * s + lg];
+                const float bv = a[(16 * K + lr) * LDA + j0 + 4 * s + lg];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[(16 * I + 4 * lg + e) * LDA + 16 * K + lr] = acc[e];
+        }
+        __syncthreads();
+    }
+    // ---- T = L^-1 -----------------------------------------------------------------------------
+    for (int idx = tid; idx < 8 * 256; idx += 256) {       // diagonal 16-blocks of T
+        const int J = idx >> 8, rr = (idx >> 4) & 15, cc = idx & 15;
+        t[(16 * J + rr) * LDA + 16 * J + cc] = dinv[J * DINV_SZ + rr * DINV_LD + cc];
+    }
+    __syncthreads();
+    for (int hb = 1; hb <= 4; hb *= 2) {                   // half size in 16-blocks
+        const int h = 16 * hb, npairs = 8 / (2 * hb), nout = npairs * hb * hb;
+        // phase A: X = L21 * T11  -> upper mirror of a
+        for (int o = w; o < nout; o += 4) {
+            const int pr = o / (hb * hb), bi = (o / hb) % hb, bj = o % hb;
+            const int c0 = pr * 2 * h;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int kb = bj; kb < hb; ++kb) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float av = a[(c0 + h + 16 * bi + lr) * LDA + c0 + 16 * kb + 4 * s + lg];
+                    const float bv = t[(c0 + 16 * kb + 4 * s + lg) * LDA + c0 + 16 * bj + lr];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[(c0 + 16 * bi + 4 * lg + e) * LDA + c0 + h + 16 * bj + lr] = acc[e];
+        }
+        __syncthreads();
+        // phase B: T21 = -T22 * X
+        for (int o = w; o < nout; o += 4) {
+            const int pr = o / (hb * hb), bi = (o / hb) % hb, bj = o % hb;
+            const int c0 = pr * 2 * h;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int kb = 0; kb <= bi; ++kb) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float av = -t[(c0 + h + 16 * bi + lr) * LDA + c0 + h + 16 * kb + 4 * s + lg];
+                    const float bv = a[(c0 + 16 * kb + 4 * s + lg) * LDA + c0 + h + 16 * bj + lr];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[(c0 + h + 16 * bi + 4 * lg + e) * LDA + c0 + 16 * bj + lr] = acc[e];
+        }
+        __syncthreads();
+    }
+    float* Tg = tinv + (int64_t)block_index * NB * NB;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+        const int r = (tid >> 5) + 8 * p, c = (tid & 31) * 4;
+        const float* q = a + r * LDA + c;
+        const float* z = t + r * LDA + c;
+        float* g = Sb + (int64_t)r * ld + c;
+        if (c + 3 <= r) *reinterpret_cast<float4*>(g) = make_float4(q[0], q[1], q[2], q[3]);
+        else {
+            if (c + 0 <= r) g[0] = q[0];
+            if (c + 1 <= r) g[1] = q[1];
+            if (c + 2 <= r) g[2] = q[2];
+        }
+        *reinterpret_cast<float4*>(Tg + r * NB + c) = make_float4(c + 0 <= r ? z[0] : 0.f, c + 1 <= r ? z[1] : 0.f,
+                                                                   c + 2 <= r ? z[2] : 0.f, c + 3 <= r ? z[3] : 0.f);
     }
 }
 
@@ -218,68 +337,109 @@ __global__ __launch_bounds__(256) void pad_identity_kernel(float* __restrict__ S
 }
 
 // ---- triangular solves (vector right-hand side, double accumulation) --------------------------
-// forward step j:  y_j = Tinv_j r_j ; r_b -= L[b,j] y_j for every block row b > j.
-// Every workgroup recomputes y_j (64 KB of Tinv from L2) instead of waiting for another launch.
-__global__ __launch_bounds__(128) void trsv_fwd_step_kernel(const float* __restrict__ L, int64_t ld, const float* __restrict__ tinv,
-                                                             int j, double* __restrict__ r, double* __restrict__ y) {
-    __shared__ double rj[NB], yj[NB];
-    const int i = threadIdx.x;
-    const int b = j + 1 + blockIdx.x;                         // block row to update (blockIdx 0 also stores y_j)
-    rj[i] = r[(int64_t)j * NB + i];
-    __syncthreads();
-    const float* Tt = tinv + ((int64_t)j * 2 + 1) * NB * NB;  // Tinv^T: (Tinv r)_i = sum_c Tt[c][i] r_c, coalesced in i
-    double s = 0.0;
-    for (int c = 0; c <= i; ++c) s += (double)Tt[c * NB + i] * rj[c];
-    yj[i] = s;
-    __syncthreads();
-    if (blockIdx.x == 0) y[(int64_t)j * NB + i] = s;
-    // r_b -= L[b, j] y_j : half-wave per row, lane = 4 consecutive columns (one 512-B row segment per half-wave)
-    const int lane = i & 63, wv = i >> 6;
-    const int sub = lane & 31, hf = lane >> 5;
-    const double y0 = yj[sub * 4], y1 = yj[sub * 4 + 1], y2 = yj[sub * 4 + 2], y3 = yj[sub * 4 + 3];
-    for (int it = 0; it < 32; ++it) {
-        const int row = wv * 64 + it * 2 + hf;
-        const float4 l4 = *reinterpret_cast<const float4*>(L + ((int64_t)b * NB + row) * ld + (int64_t)j * NB + sub * 4);
-        double u = ((double)l4.x * y0 + (double)l4.y * y1) + ((double)l4.z * y2 + (double)l4.w * y3);
-#pragma unroll
-        for (int msk = 16; msk >= 1; msk >>= 1) u += __shfl_xor(u, msk, kWave);
-        if (sub == 0) r[(int64_t)b * NB + row] -= u;
+// ONE launch per sweep.  Workgroup with ticket b owns block row b (forward) / block column b
+// (backward).  It streams its 128x128 blocks of L through LDS (prefetching the next block into
+// registers while it waits), applies each update as soon as the producing workgroup has published
+// that piece of the solution, then multiplies by the inverted diagonal block and publishes its own
+// piece.  Tickets are drawn from an atomic counter, so a workgroup only ever waits on workgroups
+// that started before it: no assumption on dispatch order or residency.  Hand-off = write-through
+// (agent-scope relaxed atomic) payload stores, vmcnt drain, barrier, one flag store; the consumer
+// polls the flag relaxed from one lane, barriers, and reads the payload with agent-scope atomic
+// loads (cdna_hip_programming.md guideline 16, form R1 with every load sc1).  Spins are bounded.
+constexpr int TLD = NB + 1;              // LDS tile row stride (odd: row- and column-walks are conflict-free)
+
+struct TrsvCtl {                         // zeroed by hipMemsetAsync before every sweep
+    unsigned ticket;
+    unsigned error;
+    unsigned pad[2];
+};
+
+// 256 threads: thread t moves 16 B at row (t>>5)+8p, column (t&31)*4 -> every row is one 512-B segment.
+// Macros, not functions: the 16 x float4 staging registers must stay in VGPRs (arrays passed by
+// reference ended up in scratch).
+#define TILE_PREFETCH(src, ldsrc)                                                                              \
+    _Pragma("unroll") for (int p = 0; p < 16; ++p)                                                             \
+        reg[p] = *reinterpret_cast<const float4*>((src) + (int64_t)((tid >> 5) + 8 * p) * (ldsrc) + (tid & 31) * 4);
+#define TILE_STORE()                                                                                           \
+    _Pragma("unroll") for (int p = 0; p < 16; ++p) {                                                           \
+        float* q = tile + ((tid >> 5) + 8 * p) * TLD + (tid & 31) * 4;                                         \
+        q[0] = reg[p].x; q[1] = reg[p].y; q[2] = reg[p].z; q[3] = reg[p].w;                                    \
     }
+
+__device__ __forceinline__ bool wait_flag(unsigned* flag, TrsvCtl* ctl, int tid, unsigned* lds_ok) {
+    if (tid == 0) {
+        unsigned ok = 1, spins = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 24) || __hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                __hip_atomic_store(&ctl->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+        }
+        *lds_ok = ok;
+    }
+    __syncthreads();
+    return *lds_ok != 0u;
 }
 
-__global__ __launch_bounds__(128) void trsv_diag_kernel(const float* __restrict__ tinv, int j, const double* __restrict__ r,
-                                                         double* __restrict__ y, int transpose) {
-    __shared__ double rj[NB];
-    const int i = threadIdx.x;
-    rj[i] = r[(int64_t)j * NB + i];
+// forward: L y = r.  transpose == 0.   backward: L^T z = y.  transpose == 1 (block index runs downwards).
+template <int TRANSPOSE>
+__global__ __launch_bounds__(256) void trsv_pipe_kernel(const float* __restrict__ L, int64_t ld, const float* __restrict__ tinv, int nb,
+                                                         const double* __restrict__ rhs, double* __restrict__ sol,
+                                                         unsigned* __restrict__ flags, TrsvCtl* __restrict__ ctl) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];        // [128][TLD]
+    __shared__ double vec[NB], part[NB];
+    __shared__ unsigned s_ticket, s_ok;
+    const int tid = threadIdx.x;
+    const int row = tid & (NB - 1), hf = tid >> 7;       // two threads per row: columns [64*hf, 64*hf+64)
+    if (tid == 0) s_ticket = atomicAdd(&ctl->ticket, 1u);
     __syncthreads();
-    const float* T = tinv + ((int64_t)j * 2 + 0) * NB * NB;
-    const float* Tt = tinv + ((int64_t)j * 2 + 1) * NB * NB;
-    double s = 0.0;
-    if (!transpose) for (int c = 0; c <= i; ++c) s += (double)Tt[c * NB + i] * rj[c];     // Tinv r
-    else for (int c = i; c < NB; ++c) s += (double)T[c * NB + i] * rj[c];                 // Tinv^T r
-    y[(int64_t)j * NB + i] = s;
-}
-
-// backward step j:  z_j = Tinv_j^T y_j ; y_c -= L[j,c]^T z_j for every block column c < j.
-__global__ __launch_bounds__(128) void trsv_bwd_step_kernel(const float* __restrict__ L, int64_t ld, const float* __restrict__ tinv,
-                                                             int j, double* __restrict__ y, double* __restrict__ z) {
-    __shared__ double yj[NB], zj[NB];
-    const int i = threadIdx.x;
-    const int c = blockIdx.x;                                 // block column to update, c < j
-    yj[i] = y[(int64_t)j * NB + i];
+    const int tk = (int)s_ticket;                       // 0 .. nb-1 in start order
+    const int b = TRANSPOSE ? nb - 1 - tk : tk;         // my block row (fwd) / block column (bwd)
+    double acc = rhs[(int64_t)b * NB + row];
+    float4 reg[16];
+    const int nsteps = tk;                              // producers: tickets 0 .. tk-1
+    // step-th producer j = step (fwd) / nb-1-step (bwd); its block is L[b, j] (fwd, j < b) or L[j, b] (bwd, j > b)
+    const float* Tb = tinv + (int64_t)b * NB * NB;
+    const float* base = TRANSPOSE ? L + (int64_t)(nb - 1) * NB * ld + (int64_t)b * NB : L + (int64_t)b * NB * ld;
+    const int64_t hop = TRANSPOSE ? -(int64_t)NB * ld : (int64_t)NB;      // pointer step from one producer's block to the next
+    if (nsteps > 0) { TILE_PREFETCH(base, ld) } else { TILE_PREFETCH(Tb, NB) }
+    for (int step = 0; step <= nsteps; ++step) {
+        const bool last = step == nsteps;               // last pass: multiply by the inverted diagonal block
+        if (!last) {
+            const int j = TRANSPOSE ? nb - 1 - step : step;
+            if (!wait_flag(&flags[j], ctl, tid, &s_ok)) return;
+            if (tid < NB) vec[tid] = __hip_atomic_load(&sol[(int64_t)j * NB + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (hf == 0) {
+            vec[row] = acc;
+        }
+        TILE_STORE()
+        __syncthreads();
+        if (!last) {
+            if (step + 1 < nsteps) { const float* nx = base + (int64_t)(step + 1) * hop; TILE_PREFETCH(nx, ld) }
+            else { TILE_PREFETCH(Tb, NB) }
+        }
+        double u = 0.0;
+        const int c0 = hf * 64;
+        if (!TRANSPOSE) {
+#pragma unroll 8
+            for (int c = c0; c < c0 + 64; ++c) u += (double)tile[row * TLD + c] * vec[c];      // row of the block
+        } else {
+#pragma unroll 8
+            for (int c = c0; c < c0 + 64; ++c) u += (double)tile[c * TLD + row] * vec[c];      // column of the block
+        }
+        if (hf == 1) part[row] = u;
+        __syncthreads();
+        if (hf == 0) {
+            if (!last) acc -= u + part[row];
+            else acc = u + part[row];
+        }
+    }
+    if (hf == 0) __hip_atomic_store(&sol[(int64_t)b * NB + row], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const float* T = tinv + ((int64_t)j * 2 + 0) * NB * NB;
-    double s = 0.0;
-    for (int k = i; k < NB; ++k) s += (double)T[k * NB + i] * yj[k];      // (Tinv^T y)_i, coalesced across i
-    zj[i] = s;
-    __syncthreads();
-    if (blockIdx.x == 0) z[(int64_t)j * NB + i] = s;
-    // y_c[i] -= sum_k L[j*NB+k][c*NB+i] z_j[k]   (coalesced across i)
-    const float* Lj = L + (int64_t)j * NB * ld + (int64_t)c * NB + i;
-    double u = 0.0;
-    for (int k = 0; k < NB; ++k) u += (double)Lj[(int64_t)k * ld] * zj[k];
-    y[(int64_t)c * NB + i] -= u;
+    if (tid == 0) __hip_atomic_store(&flags[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __global__ __launch_bounds__(256) void axpy_kernel(double* __restrict__ z, const double* __restrict__ dz, int64_t m) {
@@ -320,12 +480,12 @@ int launch_gemm(oisat_ctx* h, const char* name, float* C, int64_t ldc, const flo
 int potrf_rec(oisat_ctx* h, float* S, int64_t ld, int64_t mpb, int64_t b0, int64_t b1, float* tinv, int* info_dev) {
     if (b1 - b0 == 1) {
         const int64_t k0 = b0 * NB;
-        const size_t shm = sizeof(float) * 2 * NB * (NB + 1);
-        OISAT_LAUNCH(h, "potrf_diag", potrf_diag_kernel, dim3(1), dim3(NB), shm, S, ld, k0, tinv, info_dev, (int)b0);
+        const size_t shm = sizeof(float) * (2 * NB * LDA + 8 * DINV_SZ);
+        OISAT_LAUNCH(h, "potrf_diag", potrf_diag_kernel, dim3(1), dim3(256), shm, S, ld, k0, tinv, info_dev, (int)b0);
         const int64_t rows = (mpb - b0 - 1) * NB;
         if (rows > 0) {
             float* P = S + (k0 + NB) * ld + k0;                  // panel below the diagonal block
-            const int rc = launch_gemm(h, "trsm_gemm", P, ld, P, ld, tinv + b0 * 2 * NB * NB, NB, rows, NB, NB, 1, 0);
+            const int rc = launch_gemm(h, "trsm_gemm", P, ld, P, ld, tinv + b0 * NB * NB, NB, rows, NB, NB, 1, 0);
             if (rc) return rc;
         }
         return OISAT_OK;
@@ -345,43 +505,49 @@ int potrf_rec(oisat_ctx* h, float* S, int64_t ld, int64_t mpb, int64_t b0, int64
 
 int trsv_solve(oisat_ctx* h, const ChFactor& f, double* rhs_pad /* mp, overwritten with the solution */, double* tmp) {
     const int nb = (int)(f.mp / NB);
+    // control block: [TrsvCtl | flags[nb]] per sweep, two sweeps
+    const size_t ctl_bytes = ((sizeof(TrsvCtl) + sizeof(unsigned) * nb + 15) / 16) * 16;
+    char* ctl = (char*)oisat_ws(h, 7, 2 * ctl_bytes);
+    if (!ctl) return OISAT_ENOMEM;
+    HIP_TRY(hipMemsetAsync(ctl, 0, 2 * ctl_bytes, h->stream));
+    const size_t shm = sizeof(float) * NB * TLD;
     // forward: L y = rhs   (y -> tmp)
-    for (int j = 0; j < nb; ++j) {
-        if (j + 1 < nb) {
-            OISAT_LAUNCH(h, "trsv_fwd", trsv_fwd_step_kernel, dim3(nb - 1 - j), dim3(NB), 0, f.S, f.ld, (const float*)f.tinv, j,
-                         rhs_pad, tmp);
-        } else {
-            OISAT_LAUNCH(h, "trsv_diag", trsv_diag_kernel, dim3(1), dim3(NB), 0, (const float*)f.tinv, j, (const double*)rhs_pad,
-                         tmp, 0);
-        }
-    }
+    OISAT_LAUNCH(h, "trsv_fwd", (trsv_pipe_kernel<0>), dim3(nb), dim3(256), shm, f.S, f.ld, (const float*)f.tinv, nb,
+                 (const double*)rhs_pad, tmp, (unsigned*)(ctl + sizeof(TrsvCtl)), (TrsvCtl*)ctl);
     // backward: L^T z = y  (z -> rhs_pad)
-    for (int j = nb - 1; j >= 0; --j) {
-        if (j > 0) {
-            OISAT_LAUNCH(h, "trsv_bwd", trsv_bwd_step_kernel, dim3(j), dim3(NB), 0, f.S, f.ld, (const float*)f.tinv, j, tmp,
-                         rhs_pad);
-        } else {
-            OISAT_LAUNCH(h, "trsv_diag", trsv_diag_kernel, dim3(1), dim3(NB), 0, (const float*)f.tinv, j, (const double*)tmp,
-                         rhs_pad, 1);
-        }
-    }
+    OISAT_LAUNCH(h, "trsv_bwd", (trsv_pipe_kernel<1>), dim3(nb), dim3(256), shm, f.S, f.ld, (const float*)f.tinv, nb,
+                 (const double*)tmp, rhs_pad, (unsigned*)(ctl + ctl_bytes + sizeof(TrsvCtl)), (TrsvCtl*)(ctl + ctl_bytes));
     return OISAT_OK;
 }
 
 }  // namespace
+
+extern "C" int oisat_gemm_nt(oisat_ctx* h, float* C, int64_t ldc, const float* A, int64_t lda, const float* B, int64_t ldb,
+                             int64_t M, int64_t N, int64_t K, int mode, int lower) {
+    ARG_CHECK(h && C && A && B && M > 0 && N > 0 && K > 0);
+    ARG_CHECK(M % NB == 0 && N % NB == 0 && K % BK == 0 && K < (int64_t)INT32_MAX);
+    ARG_CHECK(ldc % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ldc >= N && lda >= K && ldb >= K);
+    ARG_CHECK(((uintptr_t)C % 16) == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0);
+    ARG_CHECK((mode == 0 || mode == 1) && (!lower || M >= N));
+    return launch_gemm(h, "gemm_nt", C, ldc, A, lda, B, ldb, M, N, (int)K, mode, lower);
+}
 
 extern "C" int oisat_potrf(oisat_ctx* h, float* S, int64_t m, int64_t ld, int* info_host) {
     ARG_CHECK(h && S && m > 0);
     const int64_t mp = cdiv(m, NB) * NB;
     ARG_CHECK(ld >= mp && (ld % 4) == 0 && ((uintptr_t)S % 16) == 0);
     const int64_t mpb = mp / NB;
-    float* tinv = (float*)oisat_ws(h, 3, sizeof(float) * mpb * 2 * NB * NB);
+    float* tinv = (float*)oisat_ws(h, 3, sizeof(float) * mpb * NB * NB);
     int* info_dev = (int*)oisat_ws(h, 4, 256);
     if (!tinv || !info_dev) return OISAT_ENOMEM;
     static bool attr_set = false;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)potrf_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)(sizeof(float) * 2 * NB * (NB + 1))));
+                                    (int)(sizeof(float) * (2 * NB * LDA + 8 * DINV_SZ))));
+        HIP_TRY(hipFuncSetAttribute((const void*)trsv_pipe_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(sizeof(float) * NB * TLD)));
+        HIP_TRY(hipFuncSetAttribute((const void*)trsv_pipe_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(sizeof(float) * NB * TLD)));
         attr_set = true;
     }
     HIP_TRY(hipMemsetAsync(info_dev, 0, sizeof(int), h->stream));

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 import threading
 
 import numpy as np
@@ -53,6 +54,7 @@ SIGNATURES = {
     "oisat_sqrt": (C.c_int, [_c_ctx, C.c_int, _ptr, _i64, _ptr]),
     "oisat_cov_build": (C.c_int, [_c_ctx, _ptr, _ptr, _ptr, _i64, C.c_double, _ptr, _i64]),
     "oisat_innovation": (C.c_int, [_c_ctx, C.c_int, _ptr, _ptr, _ptr, _i64, _ptr]),
+    "oisat_gemm_nt": (C.c_int, [_c_ctx, _ptr, _i64, _ptr, _i64, _ptr, _i64, _i64, _i64, _i64, C.c_int, C.c_int]),
     "oisat_potrf": (C.c_int, [_c_ctx, _ptr, _i64, _i64, C.POINTER(C.c_int)]),
     "oisat_potrs": (C.c_int, [_c_ctx, _ptr, _i64, _i64, _ptr]),
     "oisat_cov_residual": (C.c_int, [_c_ctx, _ptr, _ptr, _ptr, _i64, C.c_double, _ptr, _ptr, _ptr]),
@@ -94,6 +96,14 @@ def load_library():
             raise OisatUnavailable(
                 f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 f"or `make -C oi-sat-gmi_amd/csrc`.  This package has no CPU fallback.")
+        # PyTorch wheels bundle their own HIP runtime.  If this library pulls in /opt/rocm's copy first
+        # and torch is imported afterwards, torch finds "No HIP GPUs"; the other order is fine.  So when
+        # torch is installed, let it load its runtime first (OISAT_PRELOAD_TORCH=0 disables this).
+        if "torch" not in sys.modules and os.environ.get("OISAT_PRELOAD_TORCH", "1") != "0":
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         try:
             lib = C.CDLL(path)
         except OSError as e:
