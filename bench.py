@@ -4,16 +4,22 @@
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one full dense Gaussian-B analysis (innovation, covariance build, MFMA Cholesky,
-gain solve with float64-residual refinement, increment over every grid cell) of one synthetic
-month on one GPU, with the gridded background and the observations already resident in HBM.
-N = 1 workload = BASELINE.json configs[1]: 360x720 grid, 10^4 random observations, full B build +
-gain solve.  With N > 1 every rank analyses its own month (months are independent work units, as in
-the reference's one-job-per-month launch, run/job_submitter_sbatch.py:45-68): the shared grid is
-broadcast once from rank 0 and the analysis fields are gathered to rank 0 every step over RCCL.
+One "step" = one full dense Gaussian-B analysis of one synthetic month on one GPU -- innovation,
+covariance build S = H B H^T + R, fp32-MFMA Cholesky, gain solve with float64-residual refinement,
+increment B H^T z over every grid cell -- with the gridded background and the observations already
+resident in HBM when the timed region starts.
 
-Prints ONE JSON line (rank 0).  Extra legs, N = 1 only: per-kernel HIP-event timing for the
-roofline object and a bounded CPU run of the float64 oracle for cpu_baseline.
+Workload at N = 1: the configuration BASELINE.json's north star quotes its target on, which fits
+one MI355X: 0.25 deg grid (720 x 1440 = 1,036,800 cells) with 10^5 OMI-NO2-style swath
+observations (configs[2]; S alone is 40 GB of the 288 GB).  configs[1] (360 x 720, 10^4 obs) is
+timed as a secondary leg in the same run and is the size the parity tests validate end to end.
+With N > 1 every rank analyses its own month (months are independent work units, as in the
+reference's one-job-per-month launch, run/job_submitter_sbatch.py:45-68): the shared grid is
+broadcast once from rank 0 and the analysis fields are gathered every step over RCCL -- weak scaling.
+
+Prints ONE JSON line (rank 0).  Extra legs, N = 1 only: per-kernel HIP-event timing on the launch
+stream for the roofline object, the element-wise (reference-parity) OI on the same grid, and a
+bounded CPU run of the float64 oracle for cpu_baseline.
 """
 import argparse
 import json
@@ -32,60 +38,141 @@ MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md, HBM3E spec
 
 WORKLOADS = {
-    # name: (ny, nx, nobs, L_km, swaths)
-    "config2_360x720_1e4obs": (360, 720, 10000, 500.0, False),
-    "config1_72x144_1e3obs": (72, 144, 1000, 500.0, False),
-    "config3_720x1440_1e5obs_global": (720, 1440, 100000, 300.0, True),
-    "mid_360x720_3e4obs": (360, 720, 30000, 400.0, False),
+    # name: (ny, nx, nobs, L_km, swaths, refine)
+    "config3_720x1440_1e5obs": (720, 1440, 100000, 300.0, True, 1),
+    "config2_360x720_1e4obs": (360, 720, 10000, 500.0, False, 1),
+    "config1_72x144_1e3obs": (72, 144, 1000, 500.0, False, 1),
 }
+DEFAULT = "config3_720x1440_1e5obs"
+SECONDARY = "config2_360x720_1e4obs"
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="config2_360x720_1e4obs", choices=sorted(WORKLOADS))
-    ap.add_argument("--refine", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default=DEFAULT, choices=sorted(WORKLOADS))
+    ap.add_argument("--refine", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
     return ap.parse_args()
 
 
-def cpu_baseline(workload):
-    """Time the float64 oracle (oracle/oi_oracle.py dense_oi) on a bounded sample of the workload:
-    a subset of the observations and of the grid cells, sized for ~10-30 s of CPU work."""
-    from oracle import oi_oracle as orc
+def build_case(workload, seed, lat2=None, lon2=None):
     from oisatgmi import synthetic as syn, dense
-    ny, nx, nobs, L, swaths = WORKLOADS[workload]
-    m_s = min(nobs, 4000)
-    p = syn.point_obs_case(ny, nx, m_s, 424242, swaths=swaths)
-    cell = dense.regular_grid_cell(p.lat, p.lon, p.obs_lat, p.obs_lon)
-    ncell_s = min(p.Xa.size, 65536)
-    sel = np.random.default_rng(1).choice(p.Xa.size, ncell_s, replace=False)
-    lat_s, lon_s = p.lat.ravel()[sel], p.lon.ravel()[sel]
-    # observations keep pointing at real cells of the sampled grid: remap through a lookup
-    lut = -np.ones(p.Xa.size, dtype=np.int64)
-    lut[sel] = np.arange(ncell_s)
-    keep = lut[cell] >= 0
-    if keep.sum() < 16:                      # make sure the sampled cells include the observed ones
-        sel[:cell.size] = cell
-        lat_s, lon_s = p.lat.ravel()[sel], p.lon.ravel()[sel]
-        lut[:] = -1
-        lut[sel] = np.arange(ncell_s)
-        keep = lut[cell] >= 0
+    ny, nx, nobs, L, swaths, refine = WORKLOADS[workload]
+    p = syn.point_obs_case(ny, nx, nobs, seed, swaths=swaths)
+    if lat2 is None:
+        lat2, lon2 = p.lat, p.lon
+    cell = dense.regular_grid_cell(lat2, lon2, p.obs_lat, p.obs_lon)
+    return p, cell, lat2, lon2
+
+
+def make_plan(ctx, workload, seed, lat2=None, lon2=None):
+    from oisatgmi import dense
+    p, cell, lat2, lon2 = build_case(workload, seed, lat2, lon2)
+    plan = dense.DenseAnalysis(lat2, lon2, max_obs=int(p.obs_y.size), dtype=np.float32, ctx=ctx)
+    plan.load_background(p.Xa, p.Sa)
+    plan.load_obs(p.obs_lat, p.obs_lon, cell, np.where(p.obs_y < 0, 0, p.obs_y), p.obs_var)
+    return plan
+
+
+def time_steps(fn, steps, warmup, sync, barrier=None):
+    for _ in range(warmup):
+        fn()
+    sync()
+    if barrier:
+        barrier()
+    sync()
     t0 = time.perf_counter()
-    orc.dense_oi(lat_s, lon_s, p.Xa.ravel()[sel], p.Sa.ravel()[sel], p.obs_lat[keep], p.obs_lon[keep], lut[cell[keep]],
-                 np.where(p.obs_y[keep] < 0, 0, p.obs_y[keep]), p.obs_var[keep], L)
+    for _ in range(steps):
+        fn()
+    sync()
+    if barrier:
+        barrier()
+    sync()
+    return time.perf_counter() - t0
+
+
+def roofline_leg(ctx, plan, L, refine, psteps):
+    """Per-kernel durations from HIP events recorded around every launch on the launch stream."""
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    for _ in range(psteps):
+        plan.run(L, refine=refine)
+    prof = ctx.prof_collect()
+    ctx.prof_enable(False)
+    m = plan.m
+    gemm_ms = sum(prof[k]["total_ms"] for k in ("syrk_gemm", "trsm_gemm") if k in prof) / psteps
+    gemm_launches = sum(prof[k]["launches"] for k in ("syrk_gemm", "trsm_gemm") if k in prof) / psteps
+    chol_flops = m ** 3 / 3.0
+    achieved = chol_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    roof = {
+        "bound": "mfma",
+        "kernel": "gemm_nt_kernel (the syrk_gemm + trsm_gemm launches of one Cholesky factorization)",
+        "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
+        "traffic": None,
+        "algorithmic_flops_per_step": chol_flops, "kernel_ms_per_step": gemm_ms, "launches_per_step": gemm_launches,
+        "avg_launch_ms": gemm_ms / gemm_launches if gemm_launches else None,
+    }
+    per_kernel = {k: round(v["total_ms"] / psteps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
+    return roof, per_kernel
+
+
+def tier_a_leg(ctx, ny, nx, nobs, sync):
+    """Element-wise (reference-parity) OI on the same grid, device-resident: sweep + knee + analysis."""
+    from oisatgmi import synthetic as syn
+    from oisatgmi.optimal_interpolation import DiagOI
+    c = syn.diag_case(ny, nx, nobs, 3001)
+    d = DiagOI(ny * nx, dtype=np.float32, ctx=ctx)
+    d.load(c.Xa, c.Y, c.Sa, c.So)
+    el = time_steps(lambda: d.run(True), 20, 3, sync)
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    for _ in range(10):
+        idx, _ = d.run(True)
+    prof = ctx.prof_collect()
+    ctx.prof_enable(False)
+    n = ny * nx
+    apply_ms = prof["oi_apply"]["total_ms"] / prof["oi_apply"]["launches"]
+    curve_ms = prof["oi_curve"]["total_ms"] / prof["oi_curve"]["launches"]
+    gbs = DiagOI.algorithmic_bytes(n, 4) / (apply_ms * 1e-3) / 1e9
+    return {"workload": f"OI(regularization_on=True) {ny}x{nx}, {nobs} observed cells, fp32, device-resident",
+            "value": n * 20 / el, "unit": "grid-cells/s", "ms_per_call": 1e3 * el / 20, "knee_index": int(idx),
+            "kernel_ms": {"oi_curve(99 scalings)": curve_ms, "oi_apply": apply_ms},
+            "roofline_oi_apply": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes": DiagOI.algorithmic_bytes(n, 4)}}
+
+
+def cpu_baseline(workload):
+    """Time the float64 oracle (oracle/oi_oracle.py dense_oi: NumPy + SciPy Cholesky) on a bounded
+    sample of the workload -- the first `m_s` observations and a random subset of grid cells that
+    contains every observed cell -- sized for roughly 10-30 s of CPU work."""
+    from oracle import oi_oracle as orc
+    ny, nx, nobs, L, swaths, _ = WORKLOADS[workload]
+    p, cell, _, _ = build_case(workload, 424242)
+    m_s = min(int(p.obs_y.size), 5000)
+    ncell_s = min(p.Xa.size, 32768)
+    obs_cells = np.unique(cell[:m_s])
+    rest = np.setdiff1d(np.random.default_rng(1).choice(p.Xa.size, ncell_s, replace=False), obs_cells)
+    sel = np.concatenate([obs_cells, rest])[:max(ncell_s, obs_cells.size)]
+    lut = -np.ones(p.Xa.size, dtype=np.int64)
+    lut[sel] = np.arange(sel.size)
+    t0 = time.perf_counter()
+    orc.dense_oi(p.lat.ravel()[sel], p.lon.ravel()[sel], p.Xa.ravel()[sel], p.Sa.ravel()[sel], p.obs_lat[:m_s],
+                 p.obs_lon[:m_s], lut[cell[:m_s]], np.where(p.obs_y[:m_s] < 0, 0, p.obs_y[:m_s]), p.obs_var[:m_s], L)
     dt = time.perf_counter() - t0
     try:
         import threadpoolctl
         thr = max((i.get("num_threads", 1) for i in threadpoolctl.threadpool_info()), default=1)
     except Exception:
         thr = os.cpu_count() or 1
-    return {"value": ncell_s / dt, "unit": "grid-cells/s", "cores": int(thr), "kind": "port",
-            "sample": f"oracle dense_oi (float64 NumPy/SciPy) on {ncell_s} cells x {int(keep.sum())} obs of {workload}, "
-                      f"{dt:.1f} s; the full workload has {ny*nx} cells x {nobs} obs (Cholesky cost grows as obs^3)"}
+    return {"value": sel.size / dt, "unit": "grid-cells/s", "cores": int(thr), "kind": "port",
+            "sample": f"oracle dense_oi (float64 NumPy/SciPy Cholesky, BLAS threads = cores) on {sel.size} cells x {m_s} obs "
+                      f"drawn from {workload} in {dt:.1f} s; the full step has {ny*nx} cells x {int(p.obs_y.size)} obs and "
+                      f"its Cholesky cost grows as obs^3, so the CPU rate on the full step is far lower than this"}
 
 
 def main():
@@ -93,15 +180,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     os.environ.setdefault("OISAT_DEVICE", str(local))
 
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CUDA/HIP device visible); there is no CPU path")
+        raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU path")
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -109,45 +195,30 @@ def main():
 
     from oisatgmi import _hip, synthetic as syn, dense, parallel
     ctx = _hip.context()
-    stream = torch.cuda.current_stream()
-    ctx.set_stream(stream.cuda_stream)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    sync = torch.cuda.synchronize
+    barrier = dist.barrier if world > 1 else None
 
-    ny, nx, nobs, L, swaths = WORKLOADS[args.workload]
+    ny, nx, nobs, L, swaths, refine = WORKLOADS[args.workload]
+    if args.refine is not None:
+        refine = args.refine
     n = ny * nx
     # ---- shared grid: built on rank 0, broadcast once (RCCL) -------------------------------------
     lat2, lon2 = syn.global_grid(ny, nx)
     if world > 1:
         lat2, lon2 = parallel.broadcast_grid(lat2 if rank == 0 else None, lon2 if rank == 0 else None, (ny, nx), local)
     # ---- this rank's month ------------------------------------------------------------------------
-    p = syn.point_obs_case(ny, nx, nobs, 4000 + rank, swaths=swaths)
-    cell = dense.regular_grid_cell(lat2, lon2, p.obs_lat, p.obs_lon)
-    m = int(p.obs_y.size)
-    plan = dense.DenseAnalysis(lat2, lon2, max_obs=m, dtype=np.float32, ctx=ctx)
-    plan.load_background(p.Xa, p.Sa)
-    plan.load_obs(p.obs_lat, p.obs_lon, cell, np.where(p.obs_y < 0, 0, p.obs_y), p.obs_var)
+    plan = make_plan(ctx, args.workload, 4000 + rank, lat2, lon2)
+    m = plan.m
     gather = parallel.FieldGather(plan, world, rank, local) if world > 1 else None
 
     def step():
-        plan.run(L, refine=args.refine)
+        plan.run(L, refine=refine)
         if gather is not None:
             gather.run()
 
-    # one checked pass: SPD + residual (outside the timed region)
-    resid = plan.run(L, refine=args.refine, check_pd=True, want_resid=True)
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    resid = plan.run(L, refine=refine, check_pd=True, want_resid=True)      # checked pass, untimed
+    elapsed = time_steps(step, args.steps, args.warmup, sync, barrier)
     if world > 1:
         tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -155,47 +226,44 @@ def main():
 
     out = None
     if rank == 0:
-        ms = 1e3 * elapsed / args.steps
         flops = dense.DenseAnalysis.flops(m)
         out = {
-            "metric": "analysed grid-cells/s (dense Gaussian-B OI: B build + Kalman-gain solve + increment)",
+            "metric": "analysed grid-cells/s (dense Gaussian-B OI: B build + Kalman-gain solve + increment) "
+                      "and Kalman-gain solve TFLOP/s vs MI355X fp32 MFMA roofline",
             "value": world * n * args.steps / elapsed,
             "unit": "grid-cells/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms,
+            "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": args.workload, "grid": [ny, nx], "obs_per_month": m, "corr_length_km": L,
-                       "refine": args.refine, "months_per_step": world,
-                       "parallelism": "one month per GPU; RCCL broadcast of the grid, gather of fields"},
+                       "refine": refine, "months_per_step": world,
+                       "parallelism": "one month per GPU; RCCL broadcast of the grid, all-gather of fields"},
             "solve_tflops_end_to_end": world * flops / (elapsed / args.steps) / 1e12,
             "refinement_residuals": resid,
         }
-    # ---- roofline leg (N = 1): per-kernel HIP-event timing on the launch stream --------------------
-    if rank == 0 and world == 1 and not args.no_roofline:
-        ctx.prof_reset()
-        ctx.prof_enable(True)
-        psteps = max(2, min(args.steps, 5))
-        for _ in range(psteps):
-            plan.run(L, refine=args.refine)
-        prof = ctx.prof_collect()
-        ctx.prof_enable(False)
-        gemm_ms = sum(prof[k]["total_ms"] for k in ("syrk_gemm", "trsm_gemm") if k in prof) / psteps
-        gemm_launches = sum(prof[k]["launches"] for k in ("syrk_gemm", "trsm_gemm") if k in prof) / psteps
-        chol_flops = m ** 3 / 3.0
-        achieved = chol_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-        out["roofline"] = {
-            "bound": "mfma", "kernel": "gemm_nt (syrk_gemm + trsm_gemm launches of one factorization)",
-            "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
-            "traffic": None,
-            "algorithmic_flops_per_step": chol_flops, "kernel_ms_per_step": gemm_ms, "launches_per_step": gemm_launches,
-        }
-        out["kernel_ms_per_step"] = {k: v["total_ms"] / psteps for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.workload)
+    if rank == 0 and world == 1:
+        if not args.no_roofline:
+            out["roofline"], out["kernel_ms_per_step"] = roofline_leg(ctx, plan, L, refine, 2 if m > 30000 else 5)
+        del plan
+        if not args.no_secondary and args.workload != SECONDARY:
+            ny2, nx2, _, L2, _, r2 = WORKLOADS[SECONDARY]
+            plan2 = make_plan(ctx, SECONDARY, 4000)
+            plan2.run(L2, refine=r2, check_pd=True)
+            el2 = time_steps(lambda: plan2.run(L2, refine=r2), 20, 3, sync)
+            roof2, per2 = roofline_leg(ctx, plan2, L2, r2, 5)
+            out["secondary"] = {"workload": SECONDARY, "value": ny2 * nx2 * 20 / el2, "unit": "grid-cells/s",
+                                "ms_per_step": 1e3 * el2 / 20, "obs_per_month": plan2.m,
+                                "solve_tflops_end_to_end": dense.DenseAnalysis.flops(plan2.m) / (el2 / 20) / 1e12,
+                                "roofline": roof2, "kernel_ms_per_step": per2}
+            del plan2
+        if not args.no_secondary:
+            out["tier_a"] = tier_a_leg(ctx, ny, nx, nobs, sync)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -36,6 +36,51 @@ def _curve(ctx, code, dSa, dSo, n, factors):
     return mean, cnt
 
 
+class DiagOI:
+    """Device-resident element-wise OI: fields stay in HBM between calls (what ``OI`` does per call,
+    minus the PCIe copies).  ``load`` once, ``run`` many times; ``download`` when needed."""
+
+    def __init__(self, n: int, dtype=np.float32, ctx=None):
+        self.ctx = ctx or _hip.context()
+        self.dt = np.dtype(dtype)
+        self.code = _hip.dtype_code(self.dt)
+        self.n = int(n)
+        item = self.dt.itemsize
+        self.pool = self.ctx.alloc(8 * self.n * item)     # Xa | Y | Sa | So | Xb | AK | inc | err
+        self.p = [self.pool.at(i * self.n * item) for i in range(8)]
+
+    def load(self, Xa, Y, Sa, So):
+        for dst, a in zip(self.p[:4], (Xa, Y, Sa, So)):
+            self.ctx.upload_into(dst, np.ravel(a), dtype=self.dt)
+
+    def run(self, regularization_on=True, reg_index=None):
+        ctx = self.ctx
+        factors = scaling_factors(regularization_on)
+        curve = None
+        index = 0
+        if regularization_on == True:                     # noqa: E712
+            curve, _ = _curve(ctx, self.code, self.p[2], self.p[3], self.n, factors)
+            if reg_index is None:
+                k = knee_index(factors, curve)
+                index = 0 if k is None else int(k)
+            else:
+                index = int(reg_index)
+        p = self.p
+        ctx.check(ctx.lib.oisat_oi_apply(ctx.h, self.code, p[0], p[1], p[2], p[3], self.n, float(factors[index]),
+                                         p[4], p[5], p[6], p[7]))
+        return index, curve
+
+    def download(self, shape):
+        out = self.ctx.download(self.p[4], (4,) + tuple(shape), self.dt)
+        return out[0], out[1], out[2], out[3]
+
+    @staticmethod
+    def algorithmic_bytes(n: int, itemsize: int) -> int:
+        """read Xa, Y, Sa, So + write Xb, AK, inc, err (SURVEY.md section 8(d): 32 B/cell in fp32);
+        the sweep re-reads Sa and So once more."""
+        return 8 * n * itemsize
+
+
 def OI(Xa: np.ndarray, Y: np.ndarray, Sa: np.ndarray, So: np.ndarray, regularization_on=True, reg_index=None):
     '''
     Optimal interpolation between two variables looking at the exact quantity (K = ones):
