@@ -80,6 +80,13 @@ int oisat_oi_curve(oisat_ctx* h, int dtype, const void* Sa, const void* So, int6
 int oisat_oi_apply(oisat_ctx* h, int dtype, const void* Xa, void* Y_inout, const void* Sa,
                    const void* So, int64_t n, double scale, void* Xb, void* AK, void* inc, void* err);
 
+/* Fully device-side OI: sweep + knee pick (Kneedle, the algorithm of kneed.KneeLocator used at
+ * optimal_interpolation.py:37-41, restated) + analysis, no host round trip; graph-capturable.
+ * index_dev: dev int32[1] receives the chosen index; curve_dev: dev double[nscales] (may be NULL). */
+int oisat_oi_fused(oisat_ctx* h, int dtype, const void* Xa, void* Y_inout, const void* Sa,
+                   const void* So, int64_t n, const double* scales, int nscales, int forced_index,
+                   void* Xb, void* AK, void* inc, void* err, int32_t* index_dev, double* curve_dev);
+
 /* ---- monthly averaging: averaging.py:11-24 and :97-108 ---------------------------------------- */
 /* out[c] = nanmean_k stack[k][c]  (np.nanmean(axis=0), sequential-k summation like numpy).
  * stack: dev, k*n contiguous.  inf_to_nan != 0 first maps +/-inf to NaN (averaging.py:92). */

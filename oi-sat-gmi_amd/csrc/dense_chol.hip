@@ -51,27 +51,35 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(float* C, int64_t ldc, 
     const int orig = blockIdx.x;
     const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
     const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-    int ti, tj;
-    if (lower) {
-        // wg enumerates lower tiles column by column: column tj holds rows tj..ntm-1
+    // wg -> tile in ROW-BAND order: bands of 8 tile rows, inside a band column by column.  64 consecutive
+    // workgroups (what one XCD runs at once: 32 CUs x 2) are then an 8x8 patch of tiles: per K-step they
+    // pull 8 A + 8 B tiles through the XCD's L2 instead of 64 + 1 for a column strip.  In `lower` mode only
+    // tiles with ti >= tj are enumerated (the last columns of a band are partial).  The band search is a
+    // short wave-uniform loop (<= ntm/8 iterations of scalar arithmetic).
+    int ti = 0, tj = 0;
+    {
         int rem = wg;
-        tj = 0;
-        // closed form start then fix-up (ntm - tj tiles in column tj)
-        {
-            const double nn = (double)ntm;
-            double t = nn + 0.5 - sqrt((nn + 0.5) * (nn + 0.5) - 2.0 * (double)wg);
-            tj = (int)t;
-            if (tj < 0) tj = 0;
-            if (tj >= ntn) tj = ntn - 1;
-            auto col_start = [&](int c) { return (int64_t)c * ntm - (int64_t)c * (c - 1) / 2; };
-            while (tj > 0 && col_start(tj) > wg) --tj;
-            while (tj + 1 < ntn && col_start(tj + 1) <= wg) ++tj;
-            rem = wg - (int)col_start(tj);
+        for (int R0 = 0; R0 < ntm; R0 += 8) {
+            const int R1 = (R0 + 7 < ntm ? R0 + 7 : ntm - 1), nr = R1 - R0 + 1;
+            const int cmax = lower ? (R1 < ntn - 1 ? R1 : ntn - 1) : ntn - 1;       // last column of this band
+            const int cfull = lower ? (R0 < cmax ? R0 : cmax) : cmax;               // columns 0..cfull hold all nr rows
+            const int tri = cmax - cfull;                                           // partial columns cfull+1..cmax
+            const int count = nr * (cfull + 1) + tri * (R1 - cfull + 1) - tri * (tri + 1) / 2;   // + sum_{c} (R1 - c + 1)
+            if (rem < count) {
+                if (rem < nr * (cfull + 1)) {
+                    tj = rem / nr;
+                    ti = R0 + rem - tj * nr;
+                } else {
+                    rem -= nr * (cfull + 1);
+                    int c = cfull + 1;
+                    while (rem >= R1 - c + 1) { rem -= R1 - c + 1; ++c; }
+                    tj = c;
+                    ti = c + rem;
+                }
+                break;
+            }
+            rem -= count;
         }
-        ti = tj + rem;
-    } else {
-        tj = wg / ntm;
-        ti = wg - tj * ntm;
     }
     (void)ntiles_total;
     const int t = threadIdx.x;
@@ -469,8 +477,12 @@ __global__ __launch_bounds__(1024) void sumsq_kernel(const double* __restrict__ 
 int launch_gemm(oisat_ctx* h, const char* name, float* C, int64_t ldc, const float* A, int64_t lda, const float* B, int64_t ldb,
                 int64_t M, int64_t N, int K, int mode, int lower) {
     const int ntm = (int)(M / NB), ntn = (int)(N / NB);
-    int64_t ntiles = lower ? (int64_t)ntn * ntm - (int64_t)ntn * (ntn - 1) / 2 : (int64_t)ntm * ntn;
+    const int64_t ntiles = lower ? (int64_t)ntn * ntm - (int64_t)ntn * (ntn - 1) / 2 : (int64_t)ntm * ntn;
     if (ntiles <= 0) return OISAT_OK;
+    if (ntiles >= (int64_t)INT32_MAX) {
+        oisat_set_error("gemm grid too large");
+        return OISAT_EINVAL;
+    }
     OISAT_LAUNCH(h, name, gemm_nt_kernel, dim3((unsigned)ntiles), dim3(256), 0, C, ldc, A, lda, B, ldb, ntm, ntn, K, mode, lower,
                  (int)ntiles);
     return OISAT_OK;

@@ -79,26 +79,124 @@ __global__ __launch_bounds__(kCurveThreads) void oi_curve_kernel(const T* __rest
     part_cnt[wave * OISAT_MAX_SCALES + kWave + lane] = has1 ? c1 : 0u;
 }
 
-// one block of OISAT_MAX_SCALES threads: scale t adds its kCurveWaves partials in wave order
-__global__ void oi_curve_finish_kernel(const double* __restrict__ part_sum, const unsigned* __restrict__ part_cnt,
-                                       int nscales, double* __restrict__ mean_out, long long* __restrict__ cnt_out) {
-    const int t = threadIdx.x;
-    if (t >= nscales) return;
+// NumPy's pairwise summation for n < 128 (8 running sums, then the remainder), so that the device
+// knee pick uses bit-for-bit the threshold the host pick computes with np.mean(np.diff(xn)).
+__device__ double numpy_sum_small(const double* a, int n) {
+    if (n < 8) {
+        double r = 0.0;
+        for (int i = 0; i < n; ++i) r += a[i];
+        return r;
+    }
+    double r[8];
+    for (int j = 0; j < 8; ++j) r[j] = a[j];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8)
+        for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+}
+
+// Kneedle for an increasing concave curve -- the device twin of oisatgmi/_kneedle.py (itself a
+// restatement of kneed.KneeLocator(x, y, direction='increasing').knee, optimal_interpolation.py:37-39).
+// Single thread, 99 points.  Returns -1 when no knee is found (the caller falls back to index 0, :40-41).
+__device__ int kneedle_index(const double* x, const double* y, int n, double* w /* 4*n doubles of scratch */) {
+    if (n < 3) return -1;
+    double* ds = w;            // interp1d(x, y)(x): left segment evaluated at the node
+    double* xn = w + n;
+    double* df = w + 2 * n;    // difference curve
+    double* dx = w + 3 * n;
+    ds[0] = y[0];
+    for (int i = 1; i < n; ++i) {
+        const double slope = (y[i] - y[i - 1]) / (x[i] - x[i - 1]);
+        ds[i] = slope * (x[i] - x[i - 1]) + y[i - 1];
+    }
+    double xmin = x[0], xmax = x[0], ymin = ds[0], ymax = ds[0];
+    bool ynan = ds[0] != ds[0];
+    for (int i = 1; i < n; ++i) {
+        xmin = x[i] < xmin ? x[i] : xmin;
+        xmax = x[i] > xmax ? x[i] : xmax;
+        if (ds[i] != ds[i]) ynan = true;
+        ymin = ds[i] < ymin ? ds[i] : ymin;
+        ymax = ds[i] > ymax ? ds[i] : ymax;
+    }
+    if (ynan) return -1;       // np.min/np.max propagate NaN -> every comparison below is False
+    for (int i = 0; i < n; ++i) {
+        xn[i] = (x[i] - xmin) / (xmax - xmin);
+        df[i] = (ds[i] - ymin) / (ymax - ymin) - xn[i];
+    }
+    for (int i = 0; i + 1 < n; ++i) dx[i] = xn[i + 1] - xn[i];
+    const double step = fabs(numpy_sum_small(dx, n - 1) / (double)(n - 1));
+    // walk: thresholds reset at every local maximum (>= both neighbours, ends clipped), 0 at every local minimum
+    int first = -1;
+    for (int i = 0; i < n && first < 0; ++i) {
+        const double l = df[i > 0 ? i - 1 : 0], r = df[i + 1 < n ? i + 1 : n - 1];
+        if (df[i] >= l && df[i] >= r) first = i;
+    }
+    if (first < 0) return -1;
+    double thr = __builtin_nan("");
+    int at = -1;
+    for (int i = first; i < n; ++i) {
+        if (xn[i] == 1.0) return -1;
+        const double l = df[i > 0 ? i - 1 : 0], r = df[i + 1 < n ? i + 1 : n - 1];
+        if (df[i] >= l && df[i] >= r) { thr = df[i] - step; at = i; }
+        if (df[i] <= l && df[i] <= r) thr = 0.0;
+        if (df[i + 1] < thr) return at;
+    }
+    return -1;
+}
+
+// one block of 1024 threads = 128 scales x 8 slices of the per-wave partials, combined in slice order
+// (fixed order => bitwise reproducible); thread 0 then optionally picks the knee on the device.
+__global__ __launch_bounds__(1024) void oi_curve_finish_kernel(const double* __restrict__ part_sum,
+                                                                const unsigned* __restrict__ part_cnt, int nscales,
+                                                                const double* __restrict__ scales, double* __restrict__ mean_out,
+                                                                long long* __restrict__ cnt_out, int pick_knee, int forced_index,
+                                                                int* __restrict__ index_out) {
+    __shared__ double ssum[8][OISAT_MAX_SCALES];
+    __shared__ long long scnt[8][OISAT_MAX_SCALES];
+    __shared__ double scratch[4 * OISAT_MAX_SCALES];
+    __shared__ double smean[OISAT_MAX_SCALES], sx[OISAT_MAX_SCALES];
+    const int t = threadIdx.x & (OISAT_MAX_SCALES - 1), sl = threadIdx.x >> 7;
+    constexpr int per = kCurveWaves / 8;
     double s = 0.0;
     long long c = 0;
-    for (int w = 0; w < kCurveWaves; ++w) {
+    for (int w = sl * per; w < (sl + 1) * per; ++w) {
         s += part_sum[(int64_t)w * OISAT_MAX_SCALES + t];
         c += part_cnt[(int64_t)w * OISAT_MAX_SCALES + t];
     }
-    mean_out[t] = s / (double)c;      // 0/0 -> NaN like np.nanmean of an all-NaN slice
-    cnt_out[t] = c;
+    ssum[sl][t] = s;
+    scnt[sl][t] = c;
+    __syncthreads();
+    if (sl == 0 && t < nscales) {
+        double S = ssum[0][t];
+        long long Cn = scnt[0][t];
+        for (int k = 1; k < 8; ++k) { S += ssum[k][t]; Cn += scnt[k][t]; }
+        const double mean = S / (double)Cn;      // 0/0 -> NaN like np.nanmean of an all-NaN slice
+        mean_out[t] = mean;
+        cnt_out[t] = Cn;
+        smean[t] = mean;
+        sx[t] = scales[t];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && index_out) {
+        int idx = 0;
+        if (forced_index >= 0) idx = forced_index;
+        else if (pick_knee) {
+            const int k = kneedle_index(sx, smean, nscales, scratch);
+            idx = k < 0 ? 0 : k;
+        }
+        *index_out = idx;
+    }
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void oi_apply_kernel(const T* __restrict__ Xa, T* __restrict__ Y,
                                                         const T* __restrict__ Sa, const T* __restrict__ So,
-                                                        int64_t n, T s, T* __restrict__ Xb, T* __restrict__ AK,
-                                                        T* __restrict__ inc, T* __restrict__ err) {
+                                                        int64_t n, T s_host, const double* __restrict__ scales_dev,
+                                                        const int* __restrict__ idx_dev, T* __restrict__ Xb,
+                                                        T* __restrict__ AK, T* __restrict__ inc, T* __restrict__ err) {
+    const T s = idx_dev ? (T)scales_dev[*idx_dev] : s_host;      // fused path: the index was picked on the device
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         T y = Y[i];
@@ -137,35 +235,78 @@ __global__ __launch_bounds__(256) void variances_kernel(const T* __restrict__ xa
     }
 }
 
+struct CurveWs {
+    char* ws;
+    static constexpr size_t off_scales = 0;
+    static constexpr size_t off_psum = 1024;
+    static constexpr size_t off_pcnt = off_psum + sizeof(double) * kCurveWaves * OISAT_MAX_SCALES;
+    static constexpr size_t off_mean = off_pcnt + sizeof(unsigned) * kCurveWaves * OISAT_MAX_SCALES;
+    static constexpr size_t off_cnt = off_mean + sizeof(double) * OISAT_MAX_SCALES;
+    static constexpr size_t off_idx = off_cnt + sizeof(long long) * OISAT_MAX_SCALES;
+    static constexpr size_t total = off_idx + 64;
+};
+
+// enqueue sweep + finish (+ optional device knee pick); results stay in workspace slot 0
+template <typename T>
+int curve_enqueue(oisat_ctx* h, const T* Sa, const T* So, int64_t n, const double* scales, int nscales, int pick_knee,
+                  int forced_index, CurveWs& cw) {
+    cw.ws = (char*)oisat_ws(h, 0, CurveWs::total);
+    if (!cw.ws) return OISAT_ENOMEM;
+    // the scaling sweep is the same 99 numbers call after call: upload it only when it changes, so the
+    // steady-state fused path has no host synchronisation at all
+    if (h->scales_dev != cw.ws || h->scales_n != nscales || memcmp(h->scales_host, scales, sizeof(double) * nscales) != 0) {
+        char* pin = (char*)oisat_pinned(h, 4096);
+        if (!pin) return OISAT_ENOMEM;
+        HIP_TRY(hipStreamSynchronize(h->stream));          // earlier async copies may still read the staging block
+        memcpy(pin, scales, sizeof(double) * nscales);
+        HIP_TRY(hipMemcpyAsync(cw.ws + CurveWs::off_scales, pin, sizeof(double) * nscales, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        memcpy(h->scales_host, scales, sizeof(double) * nscales);
+        h->scales_n = nscales;
+        h->scales_dev = cw.ws;
+    }
+    OISAT_LAUNCH(h, "oi_curve", (oi_curve_kernel<T>), dim3(kCurveBlocks), dim3(kCurveThreads), 0, Sa, So, n,
+                 (const double*)(cw.ws + CurveWs::off_scales), nscales, (double*)(cw.ws + CurveWs::off_psum),
+                 (unsigned*)(cw.ws + CurveWs::off_pcnt));
+    OISAT_LAUNCH(h, "oi_curve_finish", oi_curve_finish_kernel, dim3(1), dim3(1024), 0, (const double*)(cw.ws + CurveWs::off_psum),
+                 (const unsigned*)(cw.ws + CurveWs::off_pcnt), nscales, (const double*)(cw.ws + CurveWs::off_scales),
+                 (double*)(cw.ws + CurveWs::off_mean), (long long*)(cw.ws + CurveWs::off_cnt), pick_knee, forced_index,
+                 (int*)(cw.ws + CurveWs::off_idx));
+    return OISAT_OK;
+}
+
 template <typename T>
 int curve_impl(oisat_ctx* h, const T* Sa, const T* So, int64_t n, const double* scales, int nscales, double* mean_out,
                int64_t* count_out) {
-    // workspace slot 0: [scales | part_sum | part_cnt | mean | cnt]
-    const size_t off_scales = 0;
-    const size_t off_psum = 1024;
-    const size_t off_pcnt = off_psum + sizeof(double) * kCurveWaves * OISAT_MAX_SCALES;
-    const size_t off_mean = off_pcnt + sizeof(unsigned) * kCurveWaves * OISAT_MAX_SCALES;
-    const size_t off_cnt = off_mean + sizeof(double) * OISAT_MAX_SCALES;
-    const size_t total = off_cnt + sizeof(long long) * OISAT_MAX_SCALES;
-    char* ws = (char*)oisat_ws(h, 0, total);
-    if (!ws) return OISAT_ENOMEM;
+    CurveWs cw;
+    const int rc = curve_enqueue<T>(h, Sa, So, n, scales, nscales, 0, -1, cw);
+    if (rc) return rc;
     char* pin = (char*)oisat_pinned(h, 4096);
-    if (!pin) return OISAT_ENOMEM;
-    memcpy(pin, scales, sizeof(double) * nscales);
-    HIP_TRY(hipMemcpyAsync(ws + off_scales, pin, sizeof(double) * nscales, hipMemcpyHostToDevice, h->stream));
-    OISAT_LAUNCH(h, "oi_curve", (oi_curve_kernel<T>), dim3(kCurveBlocks), dim3(kCurveThreads), 0, Sa, So, n,
-                 (const double*)(ws + off_scales), nscales, (double*)(ws + off_psum), (unsigned*)(ws + off_pcnt));
-    OISAT_LAUNCH(h, "oi_curve_finish", oi_curve_finish_kernel, dim3(1), dim3(OISAT_MAX_SCALES), 0,
-                 (const double*)(ws + off_psum), (const unsigned*)(ws + off_pcnt), nscales, (double*)(ws + off_mean),
-                 (long long*)(ws + off_cnt));
-    HIP_TRY(hipMemcpyAsync(pin + 1024, ws + off_mean, sizeof(double) * OISAT_MAX_SCALES + sizeof(long long) * OISAT_MAX_SCALES,
-                           hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(pin + 1024, cw.ws + CurveWs::off_mean,
+                           sizeof(double) * OISAT_MAX_SCALES + sizeof(long long) * OISAT_MAX_SCALES, hipMemcpyDeviceToHost,
+                           h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     memcpy(mean_out, pin + 1024, sizeof(double) * nscales);
     if (count_out) {
         const long long* c = (const long long*)(pin + 1024 + sizeof(double) * OISAT_MAX_SCALES);
         for (int i = 0; i < nscales; ++i) count_out[i] = (int64_t)c[i];
     }
+    return OISAT_OK;
+}
+
+template <typename T>
+int fused_impl(oisat_ctx* h, const T* Xa, T* Y, const T* Sa, const T* So, int64_t n, const double* scales, int nscales,
+               int forced_index, T* Xb, T* AK, T* inc, T* err, int32_t* index_dev, double* curve_dev) {
+    CurveWs cw;
+    const int rc = curve_enqueue<T>(h, Sa, So, n, scales, nscales, 1, forced_index, cw);
+    if (rc) return rc;
+    const int grid = stream_grid(n, 256);
+    OISAT_LAUNCH(h, "oi_apply", (oi_apply_kernel<T>), dim3(grid), dim3(256), 0, Xa, Y, Sa, So, n, T(1),
+                 (const double*)(cw.ws + CurveWs::off_scales), (const int*)(cw.ws + CurveWs::off_idx), Xb, AK, inc, err);
+    if (index_dev)
+        HIP_TRY(hipMemcpyAsync(index_dev, cw.ws + CurveWs::off_idx, sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
+    if (curve_dev)
+        HIP_TRY(hipMemcpyAsync(curve_dev, cw.ws + CurveWs::off_mean, sizeof(double) * nscales, hipMemcpyDeviceToDevice, h->stream));
     return OISAT_OK;
 }
 
@@ -180,6 +321,19 @@ extern "C" int oisat_oi_curve(oisat_ctx* h, int dtype, const void* Sa, const voi
     return curve_impl<double>(h, (const double*)Sa, (const double*)So, n, scales, nscales, mean_out, count_out);
 }
 
+extern "C" int oisat_oi_fused(oisat_ctx* h, int dtype, const void* Xa, void* Y, const void* Sa, const void* So, int64_t n,
+                              const double* scales, int nscales, int forced_index, void* Xb, void* AK, void* inc, void* err,
+                              int32_t* index_dev, double* curve_dev) {
+    ARG_CHECK(h && Xa && Y && Sa && So && scales && n > 0);
+    ARG_CHECK(nscales > 0 && nscales <= OISAT_MAX_SCALES && forced_index < nscales);
+    ARG_CHECK(dtype == OISAT_F32 || dtype == OISAT_F64);
+    if (dtype == OISAT_F32)
+        return fused_impl<float>(h, (const float*)Xa, (float*)Y, (const float*)Sa, (const float*)So, n, scales, nscales,
+                                 forced_index, (float*)Xb, (float*)AK, (float*)inc, (float*)err, index_dev, curve_dev);
+    return fused_impl<double>(h, (const double*)Xa, (double*)Y, (const double*)Sa, (const double*)So, n, scales, nscales,
+                              forced_index, (double*)Xb, (double*)AK, (double*)inc, (double*)err, index_dev, curve_dev);
+}
+
 extern "C" int oisat_oi_apply(oisat_ctx* h, int dtype, const void* Xa, void* Y, const void* Sa, const void* So, int64_t n,
                               double scale, void* Xb, void* AK, void* inc, void* err) {
     ARG_CHECK(h && Xa && Y && Sa && So && n > 0);
@@ -187,10 +341,12 @@ extern "C" int oisat_oi_apply(oisat_ctx* h, int dtype, const void* Xa, void* Y, 
     const int grid = stream_grid(n, 256);
     if (dtype == OISAT_F32) {
         OISAT_LAUNCH(h, "oi_apply", (oi_apply_kernel<float>), dim3(grid), dim3(256), 0, (const float*)Xa, (float*)Y,
-                     (const float*)Sa, (const float*)So, n, (float)scale, (float*)Xb, (float*)AK, (float*)inc, (float*)err);
+                     (const float*)Sa, (const float*)So, n, (float)scale, (const double*)nullptr, (const int*)nullptr, (float*)Xb,
+                     (float*)AK, (float*)inc, (float*)err);
     } else {
         OISAT_LAUNCH(h, "oi_apply", (oi_apply_kernel<double>), dim3(grid), dim3(256), 0, (const double*)Xa, (double*)Y,
-                     (const double*)Sa, (const double*)So, n, scale, (double*)Xb, (double*)AK, (double*)inc, (double*)err);
+                     (const double*)Sa, (const double*)So, n, scale, (const double*)nullptr, (const int*)nullptr, (double*)Xb, (double*)AK,
+                     (double*)inc, (double*)err);
     }
     return OISAT_OK;
 }

@@ -42,6 +42,10 @@ struct oisat_ctx {
     // grow-only device workspaces (never freed/reallocated inside a timed region once warm)
     void* ws[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t ws_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // last scaling sweep uploaded into workspace slot 0 (oi_diag.hip)
+    double scales_host[OISAT_MAX_SCALES] = {0};
+    int scales_n = 0;
+    const void* scales_dev = nullptr;
     // pinned host scratch for small synchronous read-backs
     void* pinned = nullptr;
     size_t pinned_bytes = 0;

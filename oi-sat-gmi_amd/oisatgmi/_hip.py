@@ -41,6 +41,8 @@ SIGNATURES = {
     "oisat_oi_curve": (C.c_int, [_c_ctx, C.c_int, _ptr, _ptr, _i64, C.POINTER(C.c_double), C.c_int,
                                  C.POINTER(C.c_double), C.POINTER(_i64)]),
     "oisat_oi_apply": (C.c_int, [_c_ctx, C.c_int, _ptr, _ptr, _ptr, _ptr, _i64, C.c_double, _ptr, _ptr, _ptr, _ptr]),
+    "oisat_oi_fused": (C.c_int, [_c_ctx, C.c_int, _ptr, _ptr, _ptr, _ptr, _i64, C.POINTER(C.c_double), C.c_int, C.c_int,
+                                 _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "oisat_nanmean_stack": (C.c_int, [_c_ctx, C.c_int, _ptr, C.c_int, _i64, C.c_int, _ptr]),
     "oisat_error_average": (C.c_int, [_c_ctx, C.c_int, _ptr, C.c_int, _i64, C.c_int, _ptr]),
     "oisat_affine": (C.c_int, [_c_ctx, C.c_int, _ptr, _i64, C.c_double, C.c_double, _ptr]),

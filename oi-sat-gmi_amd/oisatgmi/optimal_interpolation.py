@@ -70,6 +70,27 @@ class DiagOI:
                                          p[4], p[5], p[6], p[7]))
         return index, curve
 
+    def run_fused(self, regularization_on=True, reg_index=None):
+        """Sweep + knee pick + analysis entirely on the device (``oisat_oi_fused``): no host round
+        trip, nothing to wait for.  ``fused_result()`` reads back the chosen index and the curve."""
+        ctx = self.ctx
+        factors = np.ascontiguousarray(scaling_factors(regularization_on), dtype=np.float64)
+        if not hasattr(self, "_aux"):
+            self._aux = ctx.alloc(8 * _hip.MAX_SCALES + 16)          # curve | index
+        p = self.p
+        forced = -1 if reg_index is None else int(reg_index)
+        if regularization_on != True:                                 # noqa: E712
+            forced = 0
+        ctx.check(ctx.lib.oisat_oi_fused(ctx.h, self.code, p[0], p[1], p[2], p[3], self.n,
+                                         factors.ctypes.data_as(C.POINTER(C.c_double)), factors.size, forced,
+                                         p[4], p[5], p[6], p[7], self._aux.at(8 * _hip.MAX_SCALES), self._aux.ptr))
+        self._nf = factors.size
+
+    def fused_result(self):
+        curve = self.ctx.download(self._aux.ptr, (self._nf,), np.float64)
+        idx = int(self.ctx.download(self._aux.at(8 * _hip.MAX_SCALES), (1,), np.int32)[0])
+        return idx, curve
+
     def download(self, shape):
         out = self.ctx.download(self.p[4], (4,) + tuple(shape), self.dt)
         return out[0], out[1], out[2], out[3]

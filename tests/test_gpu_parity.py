@@ -136,6 +136,49 @@ def test_oi_full_size_properties(ctx):
     np.testing.assert_allclose(curve, orc.oi_curve(c.Sa, c.So, orc.scaling_factors(True)), rtol=1e-12)
 
 
+def test_fused_device_knee_matches_host_path(ctx, golden):
+    """oisat_oi_fused picks the knee on the device; it must choose what the host pick chooses and
+    produce the same fields as the two-call path -- on the golden cases and on curves of every kind."""
+    from oisatgmi.optimal_interpolation import DiagOI
+    from oisatgmi._kneedle import knee_index
+    for tag in ("72x144", "o3_72x144"):
+        g = golden(f"oi_{tag}.npz")
+        Xa, Y, Sa, So = _oi_inputs(g)
+        for dt in (np.float64, np.float32):
+            d = DiagOI(Xa.size, dtype=dt)
+            d.load(Xa, Y, Sa, So)
+            idx_host, curve_host = d.run(True)
+            ref = d.download(Xa.shape)
+            d.load(Xa, Y, Sa, So)
+            d.run_fused(True)
+            idx_dev, curve_dev = d.fused_result()
+            assert idx_dev == idx_host
+            np.testing.assert_array_equal(curve_dev, curve_host)
+            for a, b in zip(d.download(Xa.shape), ref):
+                np.testing.assert_array_equal(a, b)
+            d.run_fused(True, reg_index=37)
+            assert d.fused_result()[0] == 37
+            d.run_fused(False)
+            assert d.fused_result()[0] == 0
+    # knee pick alone on synthetic prior/obs-error mixes that move the knee across the sweep
+    rng = np.random.default_rng(123)
+    seen = set()
+    for t in range(40):
+        n = 4096
+        Sa = rng.uniform(0.01, 10.0, size=n) ** rng.uniform(0.5, 3.0)
+        So = rng.uniform(0.01, 10.0, size=n) * 10.0 ** rng.uniform(-2, 2)
+        So[rng.uniform(size=n) < 0.3] = np.nan
+        Xa = np.ones(n)
+        d = DiagOI(n, dtype=np.float64)
+        d.load(Xa, Xa, Sa, So)
+        d.run_fused(True)
+        idx_dev, curve = d.fused_result()
+        k = knee_index(np.arange(0.1, 10, 0.1), curve)
+        assert idx_dev == (0 if k is None else k)
+        seen.add(idx_dev)
+    assert len(seen) > 3
+
+
 def test_oi_edge_shapes(ctx):
     # 1 cell, odd sizes, all-NaN observations
     for shape in ((1, 1), (3, 5), (1, 129), (257, 3)):
@@ -422,3 +465,46 @@ def test_dense_config2_size_properties(ctx):
     scale = np.abs(p.Xa).max()
     assert np.abs(inc.ravel()[sel] - inc_ref).max() <= 1e-5 * scale
     assert np.abs(xa.ravel()[sel] - (p.Xa.ravel()[sel] + inc_ref)).max() <= 1e-5 * scale
+
+
+# ------------------------------------------------------------------------------------------------
+# multi-GPU plumbing on one GPU: RCCL process group of size 1 (the N>1 logic runs on CPU/gloo in
+# tests/test_parallel_cpu.py; here the device-side pieces: zero-copy view of library memory, RCCL calls)
+# ------------------------------------------------------------------------------------------------
+def test_rccl_plumbing_world_size_one(ctx):
+    import socket
+    import torch
+    import torch.distributed as dist
+    from oisatgmi import parallel
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        lat, lon = syn.global_grid(36, 72)
+        lat2, lon2 = parallel.broadcast_grid(lat, lon, (36, 72), 0)
+        np.testing.assert_array_equal(lat2, lat)
+        np.testing.assert_array_equal(lon2, lon)
+        p, cell = _dense_case(36, 72, 300, 1300)
+        plan = dense.DenseAnalysis(lat2, lon2, max_obs=300, dtype=np.float32, ctx=ctx)
+        plan.load_background(p.Xa, p.Sa)
+        plan.load_obs(p.obs_lat, p.obs_lon, cell, np.where(p.obs_y < 0, 0, p.obs_y), p.obs_var)
+        g = parallel.FieldGather(plan, 1, 0, 0)
+        plan.run(800.0, refine=1)
+        g.run()
+        torch.cuda.synchronize()
+        got = g.fields()
+        xa, inc = plan.download()
+        np.testing.assert_array_equal(got[0, 0], xa)
+        np.testing.assert_array_equal(got[0, 1], inc)
+        res = parallel.analyse_units(range(3), lambda u: torch.full((4,), float(u), device="cuda"),
+                                     result_shape=(4,), dtype=torch.float32, device="cuda")
+        assert [float(t[0]) for t in res] == [0.0, 1.0, 2.0]
+    finally:
+        ctx.set_stream(None)
+        dist.destroy_process_group()
