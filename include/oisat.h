@@ -184,6 +184,24 @@ int oisat_apply_increment(oisat_ctx* h, int dtype, const double* gxyz, const dou
                           const double* oxyz, const double* osig, const double* z, int64_t m, double g,
                           const void* xb, void* xa, void* inc);
 
+/* X <- X L^-T for nrows (multiple of 128) extra rows, X: dev float[nrows][ldx], ldx >= roundup(m,128).
+ * Same MFMA GEMMs as the factorization (block forward substitution with the inverted diagonal blocks).
+ * Must follow oisat_potrf of this L. */
+int oisat_trsm_rows(oisat_ctx* h, const float* L, int64_t m, int64_t ld, float* X, int64_t nrows, int64_t ldx);
+
+/* Posterior error sqrt(diag(B - B H^T S^-1 H B)) for grid cells [i0, i1):
+ * err_i^2 = sig_i^2 - || L^-1 (H B)_{:,i} ||^2 -- rows of (H B)^T are generated on the device in chunks of
+ * chunk_rows cells (<= 0: 4096), pushed through oisat_trsm_rows and reduced.  n*m^2 flop: meant for
+ * regional / tiled analyses.  Generalises sqrt(Sb) of optimal_interpolation.py:29,:52.  err: dev float[i1-i0]. */
+int oisat_posterior_error(oisat_ctx* h, const float* L, int64_t m, int64_t ld, const double* gxyz,
+                          const double* gsig, int64_t n, int64_t i0, int64_t i1, const double* oxyz,
+                          const double* osig, double g, int64_t chunk_rows, float* err);
+
+/* diag(K H) at the observations: ak_a = 1 - R_aa (S^-1)_aa, (S^-1)_aa = || row a of L^-T ||^2
+ * (the dense counterpart of AK = 1 - Sb/(Sa*reg), optimal_interpolation.py:31).  ak_out: dev double[m]. */
+int oisat_gain_diag(oisat_ctx* h, const float* L, int64_t m, int64_t ld, const double* ovar, int64_t chunk_rows,
+                    double* ak_out);
+
 #ifdef __cplusplus
 }
 #endif

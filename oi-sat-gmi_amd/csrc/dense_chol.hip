@@ -474,6 +474,87 @@ __global__ __launch_bounds__(1024) void sumsq_kernel(const double* __restrict__ 
     if (threadIdx.x == 0) *out = sm[0];
 }
 
+// ---- posterior diagnostics: rows of X <- X L^-T, then row norms -----------------------------------
+// rows [i0, i0+nrows) of (H B)^T: X[r][a] = sig_{i0+r} * osig_a * C(i0+r, a), zero in the padding columns
+__global__ __launch_bounds__(256) void cross_cov_rows_kernel(const double* __restrict__ gxyz, const double* __restrict__ gsig,
+                                                              int64_t n, int64_t i0, int64_t nrows, const double* __restrict__ oxyz,
+                                                              const double* __restrict__ osig, int64_t m, int64_t mp, float g2,
+                                                              float* __restrict__ X, int64_t ldx) {
+    // block = 64 rows x 64 columns tile (like cov_build): blockIdx.x = column tile, blockIdx.y = row tile
+    __shared__ float4 pr[64], pc[64];
+    const int t = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+    if (t < 64) {
+        const int64_t cell = i0 + r0 + t;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r0 + t < nrows && cell < n) v = make_float4((float)gxyz[cell], (float)gxyz[n + cell], (float)gxyz[2 * n + cell], (float)gsig[cell]);
+        pr[t] = v;
+    } else if (t < 128) {
+        const int64_t a = c0 + (t - 64);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a < m) v = make_float4((float)oxyz[a], (float)oxyz[m + a], (float)oxyz[2 * m + a], (float)osig[a]);
+        pc[t - 64] = v;
+    }
+    __syncthreads();
+    const int cx = (t & 15) * 4, ry = t >> 4;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int r = ry + rr * 16;
+        if (r0 + r >= nrows) continue;
+        const float4 a = pr[r];
+        float o[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 q = pc[cx + c];
+            const float dx = a.x - q.x, dy = a.y - q.y, dz = a.z - q.z;
+            o[c] = (c0 + cx + c < m) ? a.w * q.w * __builtin_amdgcn_exp2f(-g2 * (dx * dx + dy * dy + dz * dz)) : 0.f;
+        }
+        *reinterpret_cast<float4*>(&X[(r0 + r) * ldx + c0 + cx]) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// X = rows [a0, a0+nrows) of the identity (padded to mp columns)
+__global__ __launch_bounds__(256) void identity_rows_kernel(float* __restrict__ X, int64_t ldx, int64_t a0, int64_t nrows, int64_t mp) {
+    const int64_t total = nrows * mp;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += stride) {
+        const int64_t r = p / mp, c = p % mp;
+        X[r * ldx + c] = (c == a0 + r) ? 1.f : 0.f;
+    }
+}
+
+// out[r] = sum_c X[r][c]^2 in double; one wave per row, fixed shuffle tree
+__global__ __launch_bounds__(256) void row_sumsq_kernel(const float* __restrict__ X, int64_t nrows, int64_t ncols, int64_t ldx,
+                                                         double* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (row >= nrows) return;
+    const float* x = X + row * ldx;
+    double s = 0.0;
+    for (int64_t c = lane * 4; c < ncols; c += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(x + c);
+        s += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) s += __shfl_xor(s, k, kWave);
+    if (lane == 0) out[row] = s;
+}
+
+__global__ __launch_bounds__(256) void post_err_kernel(const double* __restrict__ gsig, int64_t i0, int64_t nrows, int64_t n,
+                                                        const double* __restrict__ ss, float* __restrict__ err) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows || i0 + r >= n) return;
+    const double v = gsig[i0 + r] * gsig[i0 + r] - ss[r];
+    err[r] = (float)sqrt(v > 0.0 ? v : 0.0);
+}
+
+__global__ __launch_bounds__(256) void gain_diag_kernel(const double* __restrict__ ovar, int64_t a0, int64_t nrows, int64_t m,
+                                                         const double* __restrict__ ss, double* __restrict__ ak) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows || a0 + r >= m) return;
+    ak[a0 + r] = 1.0 - ovar[a0 + r] * ss[r];         // diag(K H) at the observation: 1 - R_aa (S^-1)_aa
+}
+
 int launch_gemm(oisat_ctx* h, const char* name, float* C, int64_t ldc, const float* A, int64_t lda, const float* B, int64_t ldb,
                 int64_t M, int64_t N, int K, int mode, int lower) {
     const int ntm = (int)(M / NB), ntn = (int)(N / NB);
@@ -530,6 +611,22 @@ int trsv_solve(oisat_ctx* h, const ChFactor& f, double* rhs_pad /* mp, overwritt
     OISAT_LAUNCH(h, "trsv_bwd", (trsv_pipe_kernel<1>), dim3(nb), dim3(256), shm, f.S, f.ld, (const float*)f.tinv, nb,
                  (const double*)tmp, rhs_pad, (unsigned*)(ctl + ctl_bytes + sizeof(TrsvCtl)), (TrsvCtl*)(ctl + ctl_bytes));
     return OISAT_OK;
+}
+
+// X[nrows x mp] <- X L^-T  by block forward substitution over column blocks [b0, b1)
+int trsm_rows_rec(oisat_ctx* h, const ChFactor& f, float* X, int64_t nrows, int64_t ldx, int64_t b0, int64_t b1) {
+    if (b1 - b0 == 1) {
+        float* Xb = X + b0 * NB;
+        return launch_gemm(h, "trsm_rows_diag", Xb, ldx, Xb, ldx, f.tinv + b0 * NB * NB, NB, nrows, NB, NB, 1, 0);
+    }
+    const int64_t mid = b0 + (b1 - b0 + 1) / 2;
+    int rc = trsm_rows_rec(h, f, X, nrows, ldx, b0, mid);
+    if (rc) return rc;
+    // X[:, mid:b1] -= X[:, b0:mid] * L[mid:b1, b0:mid]^T
+    rc = launch_gemm(h, "trsm_rows_gemm", X + mid * NB, ldx, X + b0 * NB, ldx, f.S + mid * NB * f.ld + b0 * NB, f.ld, nrows,
+                     (b1 - mid) * NB, (int)((mid - b0) * NB), 0, 0);
+    if (rc) return rc;
+    return trsm_rows_rec(h, f, X, nrows, ldx, mid, b1);
 }
 
 }  // namespace
@@ -639,6 +736,65 @@ extern "C" int oisat_gain_solve(oisat_ctx* h, const float* L, const double* oxyz
         rc = oisat_potrs(h, L, m, ld, r);
         if (rc) return rc;
         OISAT_LAUNCH(h, "axpy", axpy_kernel, dim3(stream_grid(m, 256)), dim3(256), 0, z_out, (const double*)r, m);
+    }
+    return OISAT_OK;
+}
+
+extern "C" int oisat_trsm_rows(oisat_ctx* h, const float* L, int64_t m, int64_t ld, float* X, int64_t nrows, int64_t ldx) {
+    ARG_CHECK(h && L && X && m > 0 && nrows > 0);
+    ARG_CHECK(g_factor.S == L && g_factor.m == m && g_factor.ld == ld);     // must follow oisat_potrf of this matrix
+    ARG_CHECK(nrows % NB == 0 && ldx >= g_factor.mp && ldx % 4 == 0 && ((uintptr_t)X % 16) == 0);
+    return trsm_rows_rec(h, g_factor, X, nrows, ldx, 0, g_factor.mp / NB);
+}
+
+extern "C" int oisat_posterior_error(oisat_ctx* h, const float* L, int64_t m, int64_t ld, const double* gxyz, const double* gsig,
+                                     int64_t n, int64_t i0, int64_t i1, const double* oxyz, const double* osig, double g,
+                                     int64_t chunk_rows, float* err) {
+    ARG_CHECK(h && L && gxyz && gsig && oxyz && osig && err && m > 0 && n > 0 && 0 <= i0 && i0 < i1 && i1 <= n);
+    ARG_CHECK(g_factor.S == L && g_factor.m == m && g_factor.ld == ld);
+    const int64_t mp = g_factor.mp;
+    if (chunk_rows <= 0) chunk_rows = 4096;
+    chunk_rows = cdiv(chunk_rows, NB) * NB;
+    float* X = (float*)oisat_ws(h, 6, sizeof(float) * chunk_rows * mp + sizeof(double) * chunk_rows);
+    if (!X) return OISAT_ENOMEM;
+    double* ss = (double*)(X + chunk_rows * mp);
+    const float g2 = (float)(g * 1.4426950408889634);
+    for (int64_t c0 = i0; c0 < i1; c0 += chunk_rows) {
+        const int64_t live = (i1 - c0 < chunk_rows) ? i1 - c0 : chunk_rows;
+        const int64_t nrows = cdiv(live, NB) * NB;                 // rows live..nrows are zero rows
+        OISAT_LAUNCH(h, "cross_cov_rows", cross_cov_rows_kernel, dim3((unsigned)(mp / 64), (unsigned)(nrows / 64)), dim3(256), 0,
+                     gxyz, gsig, n, c0, live, oxyz, osig, m, mp, g2, X, mp);
+        if (nrows > live) HIP_TRY(hipMemsetAsync(X + live * mp, 0, sizeof(float) * (nrows - live) * mp, h->stream));
+        const int rc = trsm_rows_rec(h, g_factor, X, nrows, mp, 0, mp / NB);
+        if (rc) return rc;
+        OISAT_LAUNCH(h, "row_sumsq", row_sumsq_kernel, dim3((unsigned)cdiv(nrows * 64, 256)), dim3(256), 0, (const float*)X, nrows, mp,
+                     mp, ss);
+        OISAT_LAUNCH(h, "post_err", post_err_kernel, dim3((unsigned)cdiv(live, 256)), dim3(256), 0, gsig, c0, live, n,
+                     (const double*)ss, err + (c0 - i0));
+    }
+    return OISAT_OK;
+}
+
+extern "C" int oisat_gain_diag(oisat_ctx* h, const float* L, int64_t m, int64_t ld, const double* ovar, int64_t chunk_rows,
+                               double* ak_out) {
+    ARG_CHECK(h && L && ovar && ak_out && m > 0);
+    ARG_CHECK(g_factor.S == L && g_factor.m == m && g_factor.ld == ld);
+    const int64_t mp = g_factor.mp;
+    if (chunk_rows <= 0) chunk_rows = 4096;
+    chunk_rows = cdiv(chunk_rows, NB) * NB;
+    float* X = (float*)oisat_ws(h, 6, sizeof(float) * chunk_rows * mp + sizeof(double) * chunk_rows);
+    if (!X) return OISAT_ENOMEM;
+    double* ss = (double*)(X + chunk_rows * mp);
+    for (int64_t a0 = 0; a0 < m; a0 += chunk_rows) {
+        const int64_t live = (m - a0 < chunk_rows) ? m - a0 : chunk_rows;
+        const int64_t nrows = cdiv(live, NB) * NB;
+        OISAT_LAUNCH(h, "identity_rows", identity_rows_kernel, dim3(stream_grid(nrows * mp, 256)), dim3(256), 0, X, mp, a0, nrows, mp);
+        const int rc = trsm_rows_rec(h, g_factor, X, nrows, mp, 0, mp / NB);
+        if (rc) return rc;
+        OISAT_LAUNCH(h, "row_sumsq", row_sumsq_kernel, dim3((unsigned)cdiv(nrows * 64, 256)), dim3(256), 0, (const float*)X, nrows, mp,
+                     mp, ss);
+        OISAT_LAUNCH(h, "gain_diag", gain_diag_kernel, dim3((unsigned)cdiv(live, 256)), dim3(256), 0, ovar, a0, live, m,
+                     (const double*)ss, ak_out);
     }
     return OISAT_OK;
 }

@@ -104,7 +104,7 @@ class DenseAnalysis:
     def run(self, L_km: float, refine: int = 2, check_pd: bool = False, want_resid: bool = False):
         c, lib, h = self.ctx, self.ctx.lib, self.ctx.h
         m, ld = self.m, self.mp
-        g = decay_constant(L_km)
+        g = self._g = decay_constant(L_km)
         item = self.dt.itemsize
         xb, xa, inc = (self.fields.at(i * self.n * item) for i in range(3))
         c.check(lib.oisat_innovation(h, self.code, xb, self.ocell.ptr, self.oy.ptr, m, self.d.ptr))
@@ -117,6 +117,25 @@ class DenseAnalysis:
         c.check(lib.oisat_apply_increment(h, self.code, self.gxyz.ptr, self.gsig.ptr, self.n, self.oxyz.ptr,
                                           self.osig.ptr, self.z.ptr, m, g, xb, xa, inc))
         return list(resid) if want_resid else None
+
+    # ---- posterior diagnostics (after run(); they reuse the factor that run() left in HBM)
+    def posterior_error(self, chunk_rows: int = 4096):
+        """sqrt(diag(B - B H^T S^-1 H B)) on every grid cell, float32 (n m^2 flop: regional / tiled sizes)."""
+        c = self.ctx
+        if not hasattr(self, "_err"):
+            self._err = c.alloc(self.n * 4)
+        g = self._g
+        c.check(c.lib.oisat_posterior_error(c.h, self.S.ptr, self.m, self.mp, self.gxyz.ptr, self.gsig.ptr, self.n, 0, self.n,
+                                            self.oxyz.ptr, self.osig.ptr, g, int(chunk_rows), self._err.ptr))
+        return c.download(self._err.ptr, self.shape, np.float32)
+
+    def gain_diag(self, chunk_rows: int = 4096):
+        """diag(K H) at the observations (the averaging kernel of the dense analysis), float64 (m,)."""
+        c = self.ctx
+        if not hasattr(self, "_ak"):
+            self._ak = c.alloc(self.max_obs * 8)
+        c.check(c.lib.oisat_gain_diag(c.h, self.S.ptr, self.m, self.mp, self.ovar.ptr, int(chunk_rows), self._ak.ptr))
+        return c.download(self._ak.ptr, (self.m,), np.float64)
 
     # ---- outputs
     def download(self):
@@ -135,7 +154,7 @@ class DenseAnalysis:
         return m ** 3 / 3.0 + 2.0 * m ** 2
 
 
-def OI_dense(Xa, Y, Sa, So, lat, lon, L_km, scale=1.0, refine=2, obs=None, dtype=None):
+def OI_dense(Xa, Y, Sa, So, lat, lon, L_km, scale=1.0, refine=2, obs=None, dtype=None, want_error=False):
     """Dense-covariance analysis with the reference's gridded argument convention.
 
     ``Xa, Sa``: (ny, nx) background and its variance; ``Y, So``: (ny, nx) observations and their
@@ -165,8 +184,13 @@ def OI_dense(Xa, Y, Sa, So, lat, lon, L_km, scale=1.0, refine=2, obs=None, dtype
     plan.load_obs(olat, olon, cell, oy, ovar)
     resid = plan.run(L_km, refine=refine, check_pd=True, want_resid=True)
     xb, inc = plan.download()
+    extra = {}
+    if want_error:                     # the other two members of OI's 4-tuple: averaging kernel and sqrt(Sb)
+        ak = np.full(Xa.size, np.nan)
+        ak[cell] = plan.gain_diag()    # (several obs in one cell: the last one wins)
+        extra = {"ak": ak.reshape(np.shape(Xa)), "err": plan.posterior_error(), "ak_obs": plan.gain_diag()}
     bad = ~np.isfinite(Xa)
     if bad.any():
         xb = xb.copy()
         xb[bad] = np.nan
-    return xb, inc, {"nobs": int(cell.size), "residuals": resid, "cells": cell, "z": plan.download_z()}
+    return xb, inc, {"nobs": int(cell.size), "residuals": resid, "cells": cell, "z": plan.download_z(), **extra}

@@ -437,6 +437,35 @@ def test_dense_reduces_to_elementwise_oi_in_the_limit(ctx, golden):
     np.testing.assert_array_equal(xb[un], Xa[un])                       # no spread when L -> 0
 
 
+def test_dense_posterior_error_and_gain_diag(ctx, golden):
+    """The other two members of OI's 4-tuple for the dense analysis: sqrt(diag(B - B H^T S^-1 H B)) and
+    diag(K H), both via MFMA TRSM of extra rows (oisat_posterior_error / oisat_gain_diag)."""
+    for (ny, nx, m, L) in ((36, 72, 300, 800.0), (45, 90, 1100, 500.0)):
+        p, cell = _dense_case(ny, nx, m, 900 + m)
+        y = np.where(p.obs_y < 0, 0, p.obs_y)
+        ref = orc.dense_oi(p.lat, p.lon, p.Xa, p.Sa, p.obs_lat, p.obs_lon, cell, y, p.obs_var, L, want_error=True)
+        xb, inc, info = dense.OI_dense(p.Xa, None, p.Sa, None, p.lat, p.lon, L, refine=2, dtype=np.float32, want_error=True,
+                                       obs=dict(lat=p.obs_lat, lon=p.obs_lon, y=p.obs_y, var=p.obs_var))
+        sig = np.sqrt(p.Sa).max()
+        # err^2 = sig^2 - ||L^-1 HB||^2 is a difference of O(sig^2) numbers in fp32: absolute tolerance on err
+        assert np.abs(info["err"].ravel() - ref["err"]).max() <= 2e-3 * sig, np.abs(info["err"].ravel() - ref["err"]).max() / sig
+        np.testing.assert_allclose(info["ak_obs"], ref["ak_obs"], atol=2e-5, rtol=0)
+        assert (info["err"] <= np.sqrt(p.Sa) * (1 + 1e-6)).all()            # analysis never less certain than the prior
+    # reference-anchored limit: L -> 0, H = cell selection  =>  AK and sqrt(Sb) of optimal_interpolation.py:29-31,:52
+    g = golden("oi_72x144.npz")
+    Xa, Y, Sa, So = g["Xa"].copy(), g["Y"].copy(), g["Sa"].copy(), g["So"].copy()
+    lat, lon = syn.global_grid(72, 144)
+    ok = np.isfinite(Y) & np.isfinite(So) & np.isfinite(Xa) & np.isfinite(Sa)
+    xb, inc, info = dense.OI_dense(Xa, Y.copy(), Sa, So, lat, lon, L_km=1e-3, refine=1, dtype=np.float64, want_error=True)
+    ak_ref = g["off_AK"].reshape(72, 144)
+    err_ref = g["off_err"].reshape(72, 144)
+    pos = ok & (Sa > 0)                       # the reference's AK is NaN where Sa*reg == 0 (0/0)
+    np.testing.assert_allclose(info["ak"][pos], ak_ref[pos], atol=2e-6, rtol=0)
+    np.testing.assert_allclose(info["err"][pos], err_ref[pos], rtol=2e-3, atol=1e-4)
+    un = ~ok & np.isfinite(Xa)
+    np.testing.assert_allclose(info["err"][un], np.sqrt(Sa[un]), rtol=1e-6)       # unobserved: prior error untouched
+
+
 def test_dense_config2_size_properties(ctx):
     """BASELINE config 2 (360x720, 1e4 obs): too big for a quick CPU solve of everything, so check
     the solve through its float64 residual, and the analysis against the oracle on a cell subsample."""
