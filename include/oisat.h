@@ -124,6 +124,17 @@ int oisat_nn_query(oisat_ctx* h, const double* plon, const double* plat, int64_t
 int oisat_gather_mask(oisat_ctx* h, int dtype, const void* values, int64_t P, int nfields,
                       const int32_t* idx, int64_t T, void* out);
 
+/* LinearNDInterpolator(tri, values, fill_value=nan) evaluated at T targets for nfields stacked fields
+ * (_interpolosis type 1, interpolator.py:12-16).  The Delaunay triangulation is built by qhull on the
+ * host as in the reference (:153) and handed over as its arrays: simplices int32[ns][3], neighbors
+ * int32[ns][3] (-1 = hull), transform double[ns][3][2] (scipy layout: Tinv rows, then the offset
+ * vertex), vertex_to_simplex int32[P].  nn_idx: nearest swath pixel per target from oisat_nn_query
+ * (-1: masked -> NaN); the point-location walk starts there.  Outside the hull -> NaN. */
+int oisat_linear_interp(oisat_ctx* h, int dtype, const double* tlon, const double* tlat, int64_t T,
+                        const int32_t* nn_idx, const int32_t* vertex_to_simplex, const int32_t* simplices,
+                        const int32_t* neighbors, const double* transform, int64_t nsimplex,
+                        const void* values, int64_t P, int nfields, void* out);
+
 /* _upscaler fused (interpolator.py:72-91): box-average of the ky*kx window around fine node
  * idx[t] (symmetric boundary, NaN-poisoning, optional variance kernel), evaluated only at the
  * fine nodes the model cells pick; idx < 0 -> NaN.  Z: dev nfields*Ny*Nx; out: dev nfields*T. */

@@ -198,6 +198,71 @@ __global__ __launch_bounds__(256) void nn_query_kernel(const double* __restrict_
     }
 }
 
+// ---- Delaunay linear interpolation (interpolator type 1) -------------------------------------------
+// LinearNDInterpolator(tri, values, fill_value=nan)((X, Y)), interpolator.py:12-16.  The triangulation
+// itself comes from qhull on the host, exactly as in the reference (:153); what the reference then
+// repeats for every field -- point location and barycentric evaluation over ~1e6 targets -- runs here,
+// once per target for all stacked fields.  Point location is scipy's directed walk
+// (_find_simplex_directed): hop across the facet opposite the first barycentric coordinate below -eps,
+// leave the hull -> NaN; the walk starts at a simplex incident to the target's nearest swath pixel
+// (known from the neighbour search), so it takes a handful of hops.
+template <typename T>
+__global__ __launch_bounds__(256) void linear_interp_kernel(const double* __restrict__ tx, const double* __restrict__ ty, int64_t Tn,
+                                                             const int32_t* __restrict__ nn_idx, const int32_t* __restrict__ v2s,
+                                                             const int32_t* __restrict__ simplices, const int32_t* __restrict__ neighbors,
+                                                             const double* __restrict__ transform, int32_t ns, const T* __restrict__ values,
+                                                             int64_t P, int nfields, T* __restrict__ out) {
+    const double eps = 100.0 * 2.220446049250313e-16;              // scipy: eps = 100 * DBL_EPSILON
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < Tn; t += stride) {
+        const int32_t nn = nn_idx[t];
+        int32_t is = -1;
+        double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+        if (nn >= 0) {
+            const double x = tx[t], y = ty[t];
+            is = v2s[nn];
+            if (is < 0 || is >= ns) is = 0;
+            const int max_hops = 1 + ns / 4;
+            int hop = 0;
+            for (; hop < max_hops; ++hop) {
+                const double* tr = transform + (int64_t)is * 6;      // [Tinv(2x2) | r(2)]
+                const double dx = x - tr[4], dy = y - tr[5];
+                int go = -2;                                           // -2: inside; >= -1: hop target; -3: broken simplex
+                c0 = tr[0] * dx + tr[1] * dy;
+                if (c0 < -eps) go = neighbors[(int64_t)is * 3 + 0];
+                else {
+                    if (!(c0 <= 1.0 + eps)) go = -3;
+                    c1 = tr[2] * dx + tr[3] * dy;
+                    if (c1 < -eps) go = neighbors[(int64_t)is * 3 + 1];
+                    else {
+                        if (!(c1 <= 1.0 + eps)) go = -3;
+                        c2 = 1.0 - c0 - c1;
+                        if (c2 < -eps) go = neighbors[(int64_t)is * 3 + 2];
+                        else if (!(c2 <= 1.0 + eps)) go = -3;
+                    }
+                }
+                if (go == -2) break;                                   // found
+                if (go < 0) { is = -1; break; }                        // left the hull (-1) or degenerate simplex (-3)
+                is = go;
+            }
+            if (hop >= max_hops) is = -1;
+        }
+        if (is < 0) {
+            for (int f = 0; f < nfields; ++f) out[(int64_t)f * Tn + t] = nan_of<T>();
+        } else {
+            const int32_t v0 = simplices[(int64_t)is * 3], v1 = simplices[(int64_t)is * 3 + 1], v2 = simplices[(int64_t)is * 3 + 2];
+            for (int f = 0; f < nfields; ++f) {
+                const T* vf = values + (int64_t)f * P;
+                double o = 0.0;
+                o += c0 * (double)vf[v0];
+                o += c1 * (double)vf[v1];
+                o += c2 * (double)vf[v2];
+                out[(int64_t)f * Tn + t] = (T)o;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int oisat_boxfilter_symm(oisat_ctx* h, int dtype, const void* Z, int64_t Ny, int64_t Nx, int ky, int kx, int variance,
@@ -374,5 +439,23 @@ extern "C" int oisat_nn_query(oisat_ctx* h, const double* plon, const double* pl
                  sorted);
     OISAT_LAUNCH(h, "nn_query", nn_query_kernel, dim3(stream_grid(Tn, 256)), dim3(256), 0, plon, plat, tlon, tlat, Tn, g,
                  (const unsigned*)start, (const int32_t*)sorted, max_dist, idx_out, dist_out);
+    return OISAT_OK;
+}
+
+extern "C" int oisat_linear_interp(oisat_ctx* h, int dtype, const double* tlon, const double* tlat, int64_t Tn, const int32_t* nn_idx,
+                                   const int32_t* vertex_to_simplex, const int32_t* simplices, const int32_t* neighbors,
+                                   const double* transform, int64_t nsimplex, const void* values, int64_t P, int nfields, void* out) {
+    ARG_CHECK(h && tlon && tlat && nn_idx && vertex_to_simplex && simplices && neighbors && transform && values && out);
+    ARG_CHECK(Tn > 0 && nsimplex > 0 && nsimplex < (int64_t)INT32_MAX && P > 0 && nfields > 0);
+    ARG_CHECK(dtype == OISAT_F32 || dtype == OISAT_F64);
+    const int grid = stream_grid(Tn, 256);
+    if (dtype == OISAT_F32) {
+        OISAT_LAUNCH(h, "linear_interp", (linear_interp_kernel<float>), dim3(grid), dim3(256), 0, tlon, tlat, Tn, nn_idx,
+                     vertex_to_simplex, simplices, neighbors, transform, (int32_t)nsimplex, (const float*)values, P, nfields, (float*)out);
+    } else {
+        OISAT_LAUNCH(h, "linear_interp", (linear_interp_kernel<double>), dim3(grid), dim3(256), 0, tlon, tlat, Tn, nn_idx,
+                     vertex_to_simplex, simplices, neighbors, transform, (int32_t)nsimplex, (const double*)values, P, nfields,
+                     (double*)out);
+    }
     return OISAT_OK;
 }

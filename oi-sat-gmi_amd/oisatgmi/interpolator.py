@@ -13,8 +13,12 @@ Drop-in for ``oisatgmi/interpolator.py`` of the reference (``interpolator``, ``_
   never leaving HBM in between; the box average is evaluated only at the fine nodes the model
   cells pick (interpolator.py:72-91 filters the whole fine grid and throws most of it away).
 
-Types 1 (Delaunay linear) and 3 (RBF) are not implemented on the device yet and raise
-``NotImplementedError`` -- there is no silent CPU path.
+Type 1 (Delaunay linear, the reference's "recommended" default): the triangulation is built by
+qhull on the host exactly as the reference does (``Delaunay(points)``, interpolator.py:153); point
+location and barycentric evaluation -- what ``LinearNDInterpolator`` repeats for every field -- run
+on the device for all stacked fields at once (``oisat_linear_interp``).
+Type 3 (RBF) is not implemented on the device and raises ``NotImplementedError`` -- there is no
+silent CPU path.
 """
 from __future__ import annotations
 
@@ -97,6 +101,39 @@ class NNIndex:
         return d, i
 
 
+class TriIndex:
+    """Device copy of a ``scipy.spatial.Delaunay`` triangulation (simplices, neighbours, barycentric
+    transforms, one incident simplex per vertex) for ``oisat_linear_interp``."""
+
+    def __init__(self, tri):
+        self.ctx = ctx = _hip.context()
+        self.tri = tri
+        self.ns = int(tri.simplices.shape[0])
+        self.simplices = ctx.upload(tri.simplices, dtype=np.int32)
+        self.neighbors = ctx.upload(tri.neighbors, dtype=np.int32)
+        self.transform = ctx.upload(tri.transform, dtype=np.float64)
+        self.v2s = ctx.upload(tri.vertex_to_simplex, dtype=np.int32)
+        self.P = int(tri.points.shape[0])
+
+    @classmethod
+    def from_points(cls, lon, lat):
+        """None when qhull cannot triangulate (the reference returns None for the granule, :151-155)."""
+        from scipy.spatial import Delaunay
+        pts = np.column_stack((np.ravel(lon), np.ravel(lat))).astype(np.float64)
+        try:
+            return cls(Delaunay(pts))
+        except Exception:
+            return None
+
+    def interpolate(self, dt, values_buf, nfields, tgt_buf, T, nn_idx_buf):
+        ctx = self.ctx
+        out = ctx.alloc(nfields * T * dt.itemsize)
+        ctx.check(ctx.lib.oisat_linear_interp(ctx.h, _hip.dtype_code(dt), tgt_buf.at(0), tgt_buf.at(T * 8), T, nn_idx_buf.ptr,
+                                              self.v2s.ptr, self.simplices.ptr, self.neighbors.ptr, self.transform.ptr, self.ns,
+                                              values_buf.ptr, self.P, nfields, out.ptr))
+        return out
+
+
 def _gather(ctx, dt, values_buf, P, nfields, idx_buf, T):
     out = ctx.alloc(nfields * T * dt.itemsize)
     ctx.check(ctx.lib.oisat_gather_mask(ctx.h, _hip.dtype_code(dt), values_buf.ptr, P, nfields, idx_buf.ptr, T, out.ptr))
@@ -105,13 +142,29 @@ def _gather(ctx, dt, values_buf, P, nfields, idx_buf, T):
 
 def _interpolosis(interpol_func, Z: np.ndarray, X: np.ndarray, Y: np.ndarray, interpolator_type: int,
                   dists: np.ndarray, threshold: float) -> np.ndarray:
-    """One field, host in / host out (interpolator.py:10-37), types 2 and 4."""
-    if interpolator_type in (1, 3):
-        raise NotImplementedError(
-            f"interpolator_type {interpolator_type} is not implemented in the HIP backend (types 2 and 4 are)")
-    if interpolator_type not in (2, 4):
+    """One field, host in / host out (interpolator.py:10-37), types 1, 2 and 4."""
+    if interpolator_type == 3:
+        raise NotImplementedError("interpolator_type 3 (RBF) is not implemented in the HIP backend (types 1, 2 and 4 are)")
+    if interpolator_type not in (1, 2, 4):
         raise Exception("other type of interpolation methods has not been implemented yet")
     ctx = _hip.context()
+    if interpolator_type == 1:
+        ti = interpol_func if isinstance(interpol_func, TriIndex) else TriIndex(interpol_func)     # a scipy Delaunay
+        pts = ti.tri.points
+        nn = NNIndex(pts[:, 0], pts[:, 1])
+        dt = _hip.compute_dtype(Z)
+        Zb = ctx.upload(np.ravel(Z), dtype=dt)
+        T = int(np.size(X))
+        tb = ctx.alloc(2 * T * 8)
+        ctx.upload_into(tb.at(0), np.ravel(X), dtype=np.float64)
+        ctx.upload_into(tb.at(T * 8), np.ravel(Y), dtype=np.float64)
+        # walk start: nearest pixel of every target (unbounded radius here; the mask comes from `dists`)
+        span = float(np.hypot(np.ptp(pts[:, 0]) + np.ptp(np.ravel(X)), np.ptp(pts[:, 1]) + np.ptp(np.ravel(Y)))) + 1.0
+        idx, _ = nn.query_device(X, Y, span)
+        out = ti.interpolate(dt, Zb, 1, tb, T, idx)
+        ZZ = ctx.download(out.ptr, np.shape(X), dt)
+        ZZ[np.asarray(dists) > threshold * 2.0] = np.nan
+        return ZZ
     nn = NNIndex.from_any(interpol_func)
     dt = _hip.compute_dtype(Z)
     Zb = ctx.upload(np.ravel(Z), dtype=dt)
@@ -208,8 +261,16 @@ def _upscaler(X: np.ndarray, Y: np.ndarray, Z: np.ndarray, ctm_models_coordinate
 class _GranuleRegridder:
     """Everything ``interpolator()`` needs for one granule, resident in HBM."""
 
-    def __init__(self, sat_data, grid_size, ctm_models_coordinate, flag_thresh):
+    def __init__(self, sat_data, grid_size, ctm_models_coordinate, flag_thresh, interpolator_type=4):
         self.ctx = ctx = _hip.context()
+        self.kind = int(interpolator_type)
+        self.tri = None
+        self.ok = True
+        if self.kind == 1:
+            self.tri = TriIndex.from_points(sat_data.longitude_center, sat_data.latitude_center)
+            if self.tri is None:            # qhull failed: the reference skips the granule (interpolator.py:151-155)
+                self.ok = False
+                return
         ctm_latitude = ctm_models_coordinate['Latitude']
         ctm_longitude = ctm_models_coordinate['Longitude']
         dlon = np.abs(ctm_longitude[0, 0] - ctm_longitude[0, 1])
@@ -230,6 +291,10 @@ class _GranuleRegridder:
         self.idx_fine, _ = nn.query_device(self.lons_grid, self.lats_grid, 2.0 * float(grid_size))   # :145-150,:16-33
         self.plan = _upscale_plan(self.lons_grid, self.lats_grid, ctm_models_coordinate, grid_size, threshold_ctm)
         self._flag_bufs = {}
+        if self.kind == 1:
+            self.tgt = ctx.alloc(2 * self.Tfine * 8)
+            ctx.upload_into(self.tgt.at(0), np.ravel(self.lons_grid), dtype=np.float64)
+            ctx.upload_into(self.tgt.at(self.Tfine * 8), np.ravel(self.lats_grid), dtype=np.float64)
 
     def _flag(self, dt):
         b = self._flag_bufs.get(dt)
@@ -258,7 +323,10 @@ class _GranuleRegridder:
         for f in range(nf):             # field*mask (x*1.0 | x*NaN), interpolator.py:126-128,:163
             ctx.check(ctx.lib.oisat_flag_mask(ctx.h, code, raw.at(f * self.P * item), flag.ptr, self.P, self.flag_thresh,
                                               0, masked.at(f * self.P * item)))
-        fine = _gather(ctx, dt, masked, self.P, nf, self.idx_fine, self.Tfine)
+        if self.kind == 1:               # targets beyond 2*grid_size of any pixel carry idx -1 -> NaN, like the dists mask
+            fine = self.tri.interpolate(dt, masked, nf, self.tgt, self.Tfine, self.idx_fine)
+        else:
+            fine = _gather(ctx, dt, masked, self.P, nf, self.idx_fine, self.Tfine)
         if self.plan.needed:
             out = self.plan.run(fine, nf, dt, error)
             Z = ctx.download(out.ptr, (nf,) + tuple(self.plan.out_shape), dt)
@@ -276,7 +344,7 @@ def interpolator(interpolator_type: int, grid_size: float, sat_data, ctm_models_
         The interpolator function (interpolator.py:100-291)
         Input:
             interpolator_type [int]: an index specifying the type of interpolator
-                    1 > Bilinear interpolation  (not on the device yet)
+                    1 > Bilinear interpolation (Delaunay, recommended)
                     2 > Nearest neighbour
                     3 > RBF (thin_plate_spline) (not on the device yet)
                     4 > KDtree (fast nearest neighbour)
@@ -285,12 +353,13 @@ def interpolator(interpolator_type: int, grid_size: float, sat_data, ctm_models_
             ctm_models_coordinate [dic]: a dictionary containing lat and lon of the model
             flag_thresh [float]: the quality flag threshold
     '''
-    if interpolator_type in (1, 3):
-        raise NotImplementedError(
-            f"interpolator_type {interpolator_type} is not implemented in the HIP backend (types 2 and 4 are)")
-    if interpolator_type not in (2, 4):
+    if interpolator_type == 3:
+        raise NotImplementedError("interpolator_type 3 (RBF) is not implemented in the HIP backend (types 1, 2 and 4 are)")
+    if interpolator_type not in (1, 2, 4):
         raise Exception("other type of interpolation methods has not been implemented yet")
-    rg = _GranuleRegridder(sat_data, grid_size, ctm_models_coordinate, flag_thresh)
+    rg = _GranuleRegridder(sat_data, grid_size, ctm_models_coordinate, flag_thresh, interpolator_type)
+    if not rg.ok:
+        return None
     is_amf = isinstance(sat_data, satellite_amf)
     is_opt = isinstance(sat_data, satellite_opt)
 

@@ -289,8 +289,8 @@ def interpolator(interpolator_type, grid_size, sat_data, ctm_models_coordinate, 
     """``interpolator`` (interpolator.py:100-291), 2-D field path of a ``satellite_amf`` record
     (vcd, amf, tropopause if array, uncertainty) for nearest-neighbour types 2 and 4.
     Returns a ``record_type`` (positional, :289-290) or None."""
-    if interpolator_type not in (2, 4):
-        raise NotImplementedError("oracle covers nearest-neighbour types 2 and 4")
+    if interpolator_type not in (1, 2, 4):
+        raise NotImplementedError("oracle covers types 1 (Delaunay linear), 2 and 4 (nearest neighbour)")
     clat = ctm_models_coordinate["Latitude"]
     clon = ctm_models_coordinate["Longitude"]
     dlon = np.abs(clon[0, 0] - clon[0, 1])
@@ -305,8 +305,21 @@ def interpolator(interpolator_type, grid_size, sat_data, ctm_models_coordinate, 
     tree = _cKDTree(pts)
     dists, _ = tree.query(np.stack([lons, lats], axis=-1))
 
+    tri = None
+    if interpolator_type == 1:
+        from scipy.spatial import Delaunay
+        from scipy.interpolate import LinearNDInterpolator
+        try:
+            tri = Delaunay(pts)                                 # interpolator.py:151-155
+        except Exception:
+            return None
+
     def regrid(field, error=False):
-        zz = interpolosis_nn(tree, field, lons, lats, dists, grid_size)
+        if tri is not None:                                     # _interpolosis type 1, interpolator.py:12-16
+            zz = LinearNDInterpolator(tri, np.asarray(field, dtype=np.float64).flatten(), fill_value=np.nan)((lons, lats))
+            zz[dists > grid_size * 2.0] = np.nan
+        else:
+            zz = interpolosis_nn(tree, field, lons, lats, dists, grid_size)
         return upscaler(lons, lats, zz, ctm_models_coordinate, grid_size, threshold_ctm, error=error)
 
     with np.errstate(all="ignore"):

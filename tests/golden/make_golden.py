@@ -201,7 +201,7 @@ def gen_interpolator():
         out[f"{tag}_clat"] = ctm["Latitude"]
         out[f"{tag}_clon"] = ctm["Longitude"]
         out[f"{tag}_gs"] = gs
-        for it in (4, 2):
+        for it in (4, 2, 1):
             r = quiet(REF_interp.interpolator, it, gs, to_ref(g), ctm, 0.75)
             assert r is not None
             for f in ("vcd", "amf", "uncertainty", "latitude_center", "longitude_center"):

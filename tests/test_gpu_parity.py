@@ -289,7 +289,7 @@ def test_interpolator_matches_reference(ctx, golden):
     s = syn.swath_granule(5005)
     for tag in ("fine", "coarse"):
         ctm = {"Latitude": g[f"{tag}_clat"], "Longitude": g[f"{tag}_clon"]}
-        for it in (4, 2):
+        for it in (4, 2, 1):
             r = interpolator(it, float(g[f"{tag}_gs"]), s, ctm, 0.75)
             assert isinstance(r, cfg.satellite_amf)
             assert bool(r.ctm_upscaled_needed) == bool(g[f"{tag}_t{it}_need"])
@@ -298,8 +298,32 @@ def test_interpolator_matches_reference(ctx, golden):
                                            err_msg=f"{tag} type {it} {f}")
     ctm = syn.regional_ctm_grid(-80.0, -60.0, 100.0, 140.0, 2.0, 2.5)
     assert interpolator(4, 0.25, s, ctm, 0.75) is None
+    assert interpolator(1, 0.25, s, ctm, 0.75) is None
     with pytest.raises(NotImplementedError):
-        interpolator(1, 0.25, s, ctm, 0.75)
+        interpolator(3, 0.25, s, ctm, 0.75)
+    # qhull cannot triangulate collinear pixels: the reference returns None for such a granule (:151-155)
+    bad = syn.swath_granule(1, nscan=8, npix=1)
+    bad.latitude_center = np.linspace(0, 7, 8)[:, None]
+    bad.longitude_center = np.linspace(0, 7, 8)[:, None]
+    assert interpolator(1, 0.25, bad, syn.regional_ctm_grid(-2.0, 10.0, -2.0, 10.0, 1.0, 1.0), 0.75) is None
+
+
+def test_interpolosis_type1_standalone_matches_scipy(ctx):
+    """_interpolosis(tri, Z, X, Y, 1, dists, thr) with a scipy Delaunay object, as the reference calls it."""
+    from scipy.spatial import Delaunay, cKDTree
+    from scipy.interpolate import LinearNDInterpolator
+    rng = np.random.default_rng(21)
+    pts = rng.uniform(0, 10, size=(3000, 2))
+    Z = np.sin(pts[:, 0]) * np.cos(pts[:, 1])
+    Z[rng.uniform(size=Z.size) < 0.02] = np.nan
+    gx, gy = np.meshgrid(np.arange(-1, 11, 0.1), np.arange(-1, 11, 0.1))
+    dists, _ = cKDTree(pts).query(np.stack([gx, gy], axis=-1))
+    tri = Delaunay(pts)
+    want = LinearNDInterpolator(tri, Z, fill_value=np.nan)((gx, gy))
+    want[dists > 0.3 * 2.0] = np.nan
+    got = _interpolosis(tri, Z, gx, gy, 1, dists, 0.3)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-14, equal_nan=True)
 
 
 def test_interpolator_with_levels_against_oracle(ctx):

@@ -109,7 +109,7 @@ def test_interpolator(golden):
         np.testing.assert_array_equal(getattr(s, f), g["in_" + f])
     for tag in ("fine", "coarse"):
         ctm = {"Latitude": g[f"{tag}_clat"], "Longitude": g[f"{tag}_clon"]}
-        for it in (4, 2):
+        for it in (4, 2, 1):
             r = orc.interpolator(it, float(g[f"{tag}_gs"]), s, ctm, 0.75, record_type=cfg.satellite_amf)
             assert r is not None and bool(r.ctm_upscaled_needed) == bool(g[f"{tag}_t{it}_need"])
             for f in ("vcd", "amf", "uncertainty", "latitude_center", "longitude_center"):
