@@ -156,6 +156,22 @@ def tier_a_leg(ctx, ny, nx, nobs, sync):
                                   "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes": DiagOI.algorithmic_bytes(n, 4)}}
 
 
+def tiled_leg(ctx, workload, sync):
+    """BASELINE configs[2] as worded: localised block-B -- 30 deg x 30 deg tiles, halo 3 L."""
+    from oisatgmi import dense
+    ny, nx, nobs, L, swaths, refine = WORKLOADS[workload]
+    p, cell, lat2, lon2 = build_case(workload, 4000)
+    ta = dense.TiledAnalysis(lat2, lon2, tile_deg=30.0, halo_km=3.0 * L, dtype=np.float32, ctx=ctx)
+    ta.load(p.Xa, p.Sa, p.obs_lat, p.obs_lon, p.obs_y, p.obs_var)
+    ta.run(L, refine=refine, check_pd=True)
+    el = time_steps(lambda: ta.run(L, refine=refine), 3, 1, sync)
+    sizes = [int(t["obs"].size) for t in ta.tiles]
+    return {"workload": f"{workload}, localised block-B: {len(ta.tiles)} tiles of 30x30 deg, halo {3.0 * L:.0f} km",
+            "value": ny * nx * 3 / el, "unit": "grid-cells/s", "ms_per_step": 1e3 * el / 3,
+            "obs_per_tile_min_median_max": [min(sizes), int(np.median(sizes)), max(sizes)],
+            "solve_tflops_end_to_end": ta.flops / (el / 3) / 1e12}
+
+
 def cpu_baseline(workload):
     """Time the float64 oracle (oracle/oi_oracle.py dense_oi: NumPy + SciPy Cholesky) on a bounded
     sample of the workload -- the first `m_s` observations and a random subset of grid cells that
@@ -271,6 +287,7 @@ def main():
                                 "roofline": roof2, "kernel_ms_per_step": per2}
             del plan2
         if not args.no_secondary:
+            out["tiled"] = tiled_leg(ctx, args.workload, sync)
             out["tier_a"] = tier_a_leg(ctx, ny, nx, nobs, sync)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)

@@ -54,7 +54,7 @@ class DenseAnalysis:
     """Device-resident dense analysis for one grid: upload the grid once, then ``load_obs`` /
     ``run`` per month.  Buffers are sized at ``max_obs`` so nothing is allocated per analysis."""
 
-    def __init__(self, grid_lat, grid_lon, max_obs: int, dtype=np.float32, ctx=None):
+    def __init__(self, grid_lat, grid_lon, max_obs: int, dtype=np.float32, ctx=None, shared_S=None):
         self.ctx = ctx or _hip.context()
         self.dt = np.dtype(dtype)
         self.code = _hip.dtype_code(self.dt)
@@ -75,8 +75,12 @@ class DenseAnalysis:
         self.oy = c.alloc(m * 8)
         self.d = c.alloc(m * 8)
         self.z = c.alloc(m * 8)
-        self.S = c.alloc(self.mp_max * self.mp_max * 4)
+        # the factor workspace can be shared by analyses that run one after another on the stream (tiles)
+        self.S = shared_S if shared_S is not None else c.alloc(self.mp_max * self.mp_max * 4)
+        if self.S.nbytes < self.mp_max * self.mp_max * 4:
+            raise ValueError("shared_S is too small for max_obs")
         self.m = 0
+        self._direct_innovation = False
 
     # ---- inputs
     def load_background(self, Xa, Sa, scale=1.0):
@@ -86,7 +90,23 @@ class DenseAnalysis:
         self._gsig_host = sig
         c.upload_into(self.gsig.ptr, sig, dtype=np.float64)
 
+    def load_obs_direct(self, obs_lat, obs_lon, obs_sigma_b, obs_var, innovation):
+        """Observations whose background value lives outside this plan's grid (tile halos): the caller
+        supplies sigma_b at the observation and the innovation d = y - H x_b itself."""
+        m = int(np.size(innovation))
+        if m < 1 or m > self.max_obs:
+            raise ValueError(f"{m} observations; this plan was sized for 1..{self.max_obs}")
+        c = self.ctx
+        self.m = m
+        self.mp = -(-m // NB) * NB
+        c.upload_into(self.oxyz.ptr, unit_vectors(obs_lat, obs_lon))
+        c.upload_into(self.osig.ptr, np.ravel(obs_sigma_b), dtype=np.float64)
+        c.upload_into(self.ovar.ptr, np.ravel(obs_var), dtype=np.float64)
+        c.upload_into(self.d.ptr, np.ravel(innovation), dtype=np.float64)
+        self._direct_innovation = True
+
     def load_obs(self, obs_lat, obs_lon, obs_cell, obs_y, obs_var):
+        self._direct_innovation = False
         m = int(np.size(obs_y))
         if m < 1 or m > self.max_obs:
             raise ValueError(f"{m} observations; this plan was sized for 1..{self.max_obs}")
@@ -107,7 +127,8 @@ class DenseAnalysis:
         g = self._g = decay_constant(L_km)
         item = self.dt.itemsize
         xb, xa, inc = (self.fields.at(i * self.n * item) for i in range(3))
-        c.check(lib.oisat_innovation(h, self.code, xb, self.ocell.ptr, self.oy.ptr, m, self.d.ptr))
+        if not self._direct_innovation:
+            c.check(lib.oisat_innovation(h, self.code, xb, self.ocell.ptr, self.oy.ptr, m, self.d.ptr))
         c.check(lib.oisat_cov_build(h, self.oxyz.ptr, self.osig.ptr, self.ovar.ptr, m, g, self.S.ptr, ld))
         info = C.c_int(0)
         c.check(lib.oisat_potrf(h, self.S.ptr, m, ld, C.byref(info) if check_pd else None))
@@ -152,6 +173,96 @@ class DenseAnalysis:
     def flops(m: int) -> float:
         """Algorithmic flops of the gain solve as BASELINE.md counts them: m^3/3 + 2 m^2."""
         return m ** 3 / 3.0 + 2.0 * m ** 2
+
+
+def tile_partition(lat2, lon2, obs_lat, obs_lon, tile_deg=30.0, halo_km=900.0):
+    """Localised block-B (BASELINE config 3): cut a regular lat/lon grid into tile_deg x tile_deg tiles;
+    a tile is analysed with every observation inside the tile or within ``halo_km`` of it (3 L is the
+    usual choice: exp(-9/2) = 1 % correlation left).  Returns a list of dicts with the tile's grid
+    slices and the indices of its observations.  Longitude wraps; bands whose halo reaches a pole take
+    every longitude."""
+    lat2 = np.asarray(lat2)
+    lon2 = np.asarray(lon2)
+    ny, nx = lat2.shape
+    latc, lonc = lat2[:, 0], lon2[0, :]
+    dlat, dlon = abs(latc[1] - latc[0]), abs(lonc[1] - lonc[0])
+    ty, tx = max(1, int(round(tile_deg / dlat))), max(1, int(round(tile_deg / dlon)))
+    h_lat = np.rad2deg(halo_km / EARTH_RADIUS_KM)
+    olat, olon = np.ravel(obs_lat), np.ravel(obs_lon)
+    tiles = []
+    for y0 in range(0, ny, ty):
+        y1 = min(y0 + ty, ny)
+        la0, la1 = latc[y0] - dlat / 2, latc[y1 - 1] + dlat / 2
+        in_lat = (olat >= la0 - h_lat) & (olat <= la1 + h_lat)
+        worst = max(abs(la0 - h_lat), abs(la1 + h_lat))
+        h_lon = 360.0 if worst >= 89.0 else h_lat / np.cos(np.deg2rad(worst))
+        for x0 in range(0, nx, tx):
+            x1 = min(x0 + tx, nx)
+            lo0, lo1 = lonc[x0] - dlon / 2, lonc[x1 - 1] + dlon / 2
+            mid, half = 0.5 * (lo0 + lo1), 0.5 * (lo1 - lo0) + h_lon
+            dl = np.abs((olon - mid + 180.0) % 360.0 - 180.0)
+            sel = np.flatnonzero(in_lat & (dl <= half))
+            tiles.append({"rows": (y0, y1), "cols": (x0, x1), "obs": sel})
+    return tiles
+
+
+class TiledAnalysis:
+    """Localised block-B analysis: one small dense analysis per tile (its own S = H B H^T + R over the
+    tile's observations + halo), run back to back on the stream with ONE shared factor workspace.
+    Tiles are independent work units -- ``parallel.shard_units`` spreads (month x tile) over GPUs."""
+
+    def __init__(self, grid_lat, grid_lon, tile_deg=30.0, halo_km=900.0, dtype=np.float32, ctx=None):
+        self.ctx = ctx or _hip.context()
+        self.lat2, self.lon2 = np.asarray(grid_lat), np.asarray(grid_lon)
+        self.tile_deg, self.halo_km = float(tile_deg), float(halo_km)
+        self.dt = np.dtype(dtype)
+        self.plans = []
+
+    def load(self, Xa, Sa, obs_lat, obs_lon, obs_y, obs_var, scale=1.0):
+        Xa = np.asarray(Xa, dtype=np.float64)
+        sig = np.sqrt(float(scale) * np.asarray(Sa, dtype=np.float64))
+        olat, olon = np.ravel(obs_lat), np.ravel(obs_lon)
+        cell = regular_grid_cell(self.lat2, self.lon2, olat, olon)
+        y = np.where(np.ravel(obs_y) < 0, 0.0, np.ravel(obs_y))
+        d_all = y - Xa.ravel()[cell]                         # innovation against the GLOBAL background
+        s_all = sig.ravel()[cell]
+        ovar = np.ravel(obs_var)
+        self.tiles = [t for t in tile_partition(self.lat2, self.lon2, olat, olon, self.tile_deg, self.halo_km)]
+        mmax = max((t["obs"].size for t in self.tiles), default=0)
+        mp = -(-max(mmax, 1) // NB) * NB
+        self.S = self.ctx.alloc(mp * mp * 4)
+        self.plans = []
+        for t in self.tiles:
+            (y0, y1), (x0, x1) = t["rows"], t["cols"]
+            if t["obs"].size == 0:
+                self.plans.append(None)
+                continue
+            p = DenseAnalysis(self.lat2[y0:y1, x0:x1], self.lon2[y0:y1, x0:x1], max_obs=int(t["obs"].size), dtype=self.dt,
+                              ctx=self.ctx, shared_S=self.S)
+            p.load_background(Xa[y0:y1, x0:x1], np.asarray(Sa)[y0:y1, x0:x1], scale=scale)
+            o = t["obs"]
+            p.load_obs_direct(olat[o], olon[o], s_all[o], ovar[o], d_all[o])
+            self.plans.append(p)
+        self._Xa = Xa
+        self.n = int(Xa.size)
+        self.flops = sum(DenseAnalysis.flops(int(t["obs"].size)) for t in self.tiles if t["obs"].size)
+
+    def run(self, L_km, refine=1, check_pd=False):
+        for p in self.plans:
+            if p is not None:
+                p.run(L_km, refine=refine, check_pd=check_pd)
+
+    def download(self):
+        xa = self._Xa.astype(self.dt).copy()
+        inc = np.zeros_like(xa)
+        for t, p in zip(self.tiles, self.plans):
+            if p is None:
+                continue
+            (y0, y1), (x0, x1) = t["rows"], t["cols"]
+            a, b = p.download()
+            xa[y0:y1, x0:x1] = a
+            inc[y0:y1, x0:x1] = b
+        return xa, inc
 
 
 def OI_dense(Xa, Y, Sa, So, lat, lon, L_km, scale=1.0, refine=2, obs=None, dtype=None, want_error=False):

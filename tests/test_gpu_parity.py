@@ -490,6 +490,50 @@ def test_dense_posterior_error_and_gain_diag(ctx, golden):
     np.testing.assert_allclose(info["err"][un], np.sqrt(Sa[un]), rtol=1e-6)       # unobserved: prior error untouched
 
 
+def test_tiled_block_b_analysis(ctx):
+    """Localised block-B (tiles + halo): each tile against the float64 oracle on the same observation set;
+    with a halo that covers the globe every tile sees every observation and the result is the global one."""
+    ny, nx, m, L = 36, 72, 900, 400.0
+    p, cell = _dense_case(ny, nx, m, 4321)
+    y = np.where(p.obs_y < 0, 0, p.obs_y)
+    ta = dense.TiledAnalysis(p.lat, p.lon, tile_deg=60.0, halo_km=3 * L, dtype=np.float32)
+    ta.load(p.Xa, p.Sa, p.obs_lat, p.obs_lon, p.obs_y, p.obs_var)
+    covered = np.zeros((ny, nx), dtype=int)
+    for t in ta.tiles:
+        covered[t["rows"][0]:t["rows"][1], t["cols"][0]:t["cols"][1]] += 1
+    assert (covered == 1).all() and len(ta.tiles) == 3 * 6
+    ta.run(L, refine=2, check_pd=True)
+    xa, inc = ta.download()
+    scale = np.abs(p.Xa).max()
+    for t in ta.tiles:
+        (y0, y1), (x0, x1) = t["rows"], t["cols"]
+        o = t["obs"]
+        # every observation inside the tile must be in its list; the halo adds more
+        inside = (cell // nx >= y0) & (cell // nx < y1) & (cell % nx >= x0) & (cell % nx < x1)
+        assert np.isin(np.flatnonzero(inside), o).all() and o.size >= inside.sum()
+        sub = (slice(y0, y1), slice(x0, x1))
+        # oracle on the tile: the innovation uses the global background at the obs cell
+        lut = np.full(ny * nx, -1, dtype=np.int64)
+        tile_cells = (np.arange(y0, y1)[:, None] * nx + np.arange(x0, x1)[None, :]).ravel()
+        lut[tile_cells] = np.arange(tile_cells.size)
+        sb = np.sqrt(p.Sa.ravel())
+        po = orc.unit_vectors(p.obs_lat[o], p.obs_lon[o])
+        S = orc.gaussian_corr(po, po, L) * sb[cell[o]][:, None] * sb[cell[o]][None, :]
+        S[np.diag_indices_from(S)] += p.obs_var[o]
+        z = np.linalg.solve(S, y[o] - p.Xa.ravel()[cell[o]])
+        pg = orc.unit_vectors(p.lat[sub].ravel(), p.lon[sub].ravel())
+        inc_ref = sb[tile_cells] * (orc.gaussian_corr(pg, po, L) @ (sb[cell[o]] * z))
+        assert np.abs(inc[sub].ravel() - inc_ref).max() <= 1e-5 * scale
+    # global halo == global analysis
+    tb = dense.TiledAnalysis(p.lat, p.lon, tile_deg=90.0, halo_km=25000.0, dtype=np.float32)
+    tb.load(p.Xa, p.Sa, p.obs_lat, p.obs_lon, p.obs_y, p.obs_var)
+    assert all(t["obs"].size == m for t in tb.tiles)
+    tb.run(L, refine=2)
+    xg, _ = tb.download()
+    ref = orc.dense_oi(p.lat, p.lon, p.Xa, p.Sa, p.obs_lat, p.obs_lon, cell, y, p.obs_var, L)
+    assert np.abs(xg.ravel() - ref["xa"]).max() <= 1e-5 * scale
+
+
 def test_dense_config2_size_properties(ctx):
     """BASELINE config 2 (360x720, 1e4 obs): too big for a quick CPU solve of everything, so check
     the solve through its float64 residual, and the analysis against the oracle on a cell subsample."""
