@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="process-group backend; gloo only to rehearse N>1 on a 1-GPU box")
+    ap.add_argument("--rehearse-on-device0", action="store_true", help="every rank uses GPU 0 (rehearsal only)")
     return ap.parse_args()
 
 
@@ -208,7 +210,9 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world == 1 and args.gpus > 1:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    os.environ.setdefault("OISAT_DEVICE", str(local))
+    if args.rehearse_on_device0:
+        local = 0
+    os.environ["OISAT_DEVICE"] = str(local)
 
     import torch
     import torch.distributed as dist
@@ -217,13 +221,15 @@ def main():
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from oisatgmi import _hip, synthetic as syn, dense, parallel
     ctx = _hip.context()
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     sync = torch.cuda.synchronize
     barrier = dist.barrier if world > 1 else None
+    if world > 1:
+        torch.zeros(1, device="cuda").add_(1)            # make sure the device context exists before the collectives
 
     ny, nx, nobs, L, swaths, refine = WORKLOADS[args.workload]
     if args.refine is not None:

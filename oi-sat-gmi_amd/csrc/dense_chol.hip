@@ -237,11 +237,14 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(float* __restrict__ S, 
         }
     }
     __syncthreads();
+    // Look-ahead: while waves 1-3 apply the trailing update of block column J, wave 0 updates only the next
+    // diagonal block and immediately factors/inverts it, so the serial 16x16 factorizations (the longest
+    // single-wave stretch) hide behind the MFMA updates instead of adding to them.
+    if (w == 0) diag16_factor_invert(a, 0, dinv, info, (int)k0, lane);
+    __syncthreads();
     for (int J = 0; J < 8; ++J) {
         const int j0 = 16 * J;
-        float* dJ = dinv + J * DINV_SZ;
-        if (w == 0) diag16_factor_invert(a, j0, dJ, info, (int)(k0 + j0), lane);
-        __syncthreads();
+        const float* dJ = dinv + J * DINV_SZ;
         for (int I = J + 1 + w; I < 8; I += 4) {          // panel: P_I = A[I,J] * Dinv^T
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -254,8 +257,10 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(float* __restrict__ S, 
             for (int e = 0; e < 4; ++e) a[(16 * I + 4 * lg + e) * LDA + j0 + lr] = acc[e];
         }
         __syncthreads();
-        const int n = 7 - J, np = n * (n + 1) / 2;        // trailing pairs (I >= K > J)
-        for (int p = w; p < np; p += 4) {
+        if (J == 7) break;
+        const int n = 7 - J, np = n * (n + 1) / 2;        // trailing pairs (I >= K > J); pair 0 = (J+1, J+1)
+        const int pfirst = (w == 0) ? 0 : w, pstep = (w == 0) ? np : 3;          // wave 0: pair 0 only
+        for (int p = pfirst; p < np; p += pstep) {
             int kk = 0, rem = p;
             while (rem >= n - kk) { rem -= n - kk; ++kk; }
             const int K = J + 1 + kk, I = K + rem;
@@ -271,6 +276,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(float* __restrict__ S, 
 #pragma unroll
             for (int e = 0; e < 4; ++e) a[(16 * I + 4 * lg + e) * LDA + 16 * K + lr] = acc[e];
         }
+        if (w == 0) diag16_factor_invert(a, j0 + 16, dinv + (J + 1) * DINV_SZ, info, (int)(k0 + j0 + 16), lane);
         __syncthreads();
     }
     // ---- T = L^-1 -----------------------------------------------------------------------------

@@ -72,7 +72,7 @@ def broadcast_grid(lat, lon, shape, local_rank=None):
     """The shared model grid: rank 0 -> everyone (RCCL over xGMI when the backend is nccl)."""
     import torch
     dist = _dist()
-    dev = torch.device("cuda", local_rank) if dist.get_backend() == "nccl" else torch.device("cpu")
+    dev = torch.device("cuda", local_rank) if (dist.get_backend() == "nccl" and local_rank is not None) else torch.device("cpu")
     lat2, lon2 = broadcast_arrays([lat, lon], [shape, shape], torch.float64, dev)
     return lat2, lon2
 
@@ -115,7 +115,12 @@ class FieldGather:
         self.shape = plan.shape
 
     def run(self):
-        _dist().all_gather_into_tensor(self.slab, self.send)
+        dist = _dist()
+        if dist.get_backend() == "nccl":
+            dist.all_gather_into_tensor(self.slab, self.send)       # RCCL, device to device over xGMI
+        else:                                                       # rehearsal backends (gloo): list form
+            parts = [self.slab[r] for r in range(self.world)]
+            dist.all_gather(parts, self.send)
         return self.slab
 
     def fields(self):
