@@ -15,8 +15,12 @@
 //     hit 16 distinct 4-bank slots per 16-lane group)
 //   * a lane reads k = 8s+4h..+3 as one ds_read_b128 and feeds 4 consecutive MFMAs; A and B use
 //     the same k permutation, so the product is unchanged
-//   * global->register prefetch of tile t+1 is issued before the MFMAs of tile t and written to
-//     the other LDS buffer after them (one barrier per K-tile)
+//   * software pipeline, skewed across the barrier: the fragments of MFMA group s+1 are read from
+//     LDS while group s runs (two fragment register sets); the one barrier per K-tile sits before
+//     the LAST group, so the first fragments of tile t+1 are fetched behind 16 MFMAs instead of in
+//     front of an idle pipe (measured +7 %: 129 -> 138 TFLOP/s at 8192^3)
+//   * global->register prefetch of tile t+1 is issued at the top of tile t and parked in the other
+//     LDS buffer half-way through its MFMAs
 //   * blockIdx -> tile map keeps each XCD (private 4 MiB L2) on a contiguous strip of tiles that
 //     share B rows
 // The 128x128 diagonal blocks are factored and inverted by one workgroup in LDS; the panel below
@@ -123,26 +127,38 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(float* C, int64_t ldc, 
     OISAT_LSTORE(0);
     __syncthreads();
     const int frow = lane & 31, fh = lane >> 5;
+    const int aoff = (wr * 64 + frow) * LDSW + 4 * fh, boff = (wc * 64 + frow) * LDSW + 4 * fh;
+    // fragment registers, two sets: the operands of MFMA group s+1 are read from LDS while group s runs
+    float4 fa0, fa1, fb0, fb1, ga0, ga1, gb0, gb1;
+#define OISAT_FRAG(A0, A1, B0, B1, buf, s)                                                      \
+    do {                                                                                        \
+        A0 = *reinterpret_cast<const float4*>(&lds[buf][0][aoff + 8 * (s)]);                    \
+        A1 = *reinterpret_cast<const float4*>(&lds[buf][0][aoff + 32 * LDSW + 8 * (s)]);        \
+        B0 = *reinterpret_cast<const float4*>(&lds[buf][1][boff + 8 * (s)]);                    \
+        B1 = *reinterpret_cast<const float4*>(&lds[buf][1][boff + 32 * LDSW + 8 * (s)]);        \
+    } while (0)
+#define OISAT_MFMA4(A0, A1, B0, B1, c)                                                          \
+    acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.c, B0.c, acc00, 0, 0, 0);                   \
+    acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.c, B1.c, acc01, 0, 0, 0);                   \
+    acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.c, B0.c, acc10, 0, 0, 0);                   \
+    acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.c, B1.c, acc11, 0, 0, 0);
+#define OISAT_MFMA16(A0, A1, B0, B1)                                                            \
+    OISAT_MFMA4(A0, A1, B0, B1, x) OISAT_MFMA4(A0, A1, B0, B1, y) OISAT_MFMA4(A0, A1, B0, B1, z) OISAT_MFMA4(A0, A1, B0, B1, w)
+    OISAT_FRAG(fa0, fa1, fb0, fb1, 0, 0);
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nkt) OISAT_GLOAD((kt + 1) * BK);
-        const float* la = &lds[cur][0][(wr * 64 + frow) * LDSW + 4 * fh];
-        const float* lb = &lds[cur][1][(wc * 64 + frow) * LDSW + 4 * fh];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const float4 a0 = *reinterpret_cast<const float4*>(la + 8 * s);
-            const float4 a1 = *reinterpret_cast<const float4*>(la + 32 * LDSW + 8 * s);
-            const float4 b0 = *reinterpret_cast<const float4*>(lb + 8 * s);
-            const float4 b1 = *reinterpret_cast<const float4*>(lb + 32 * LDSW + 8 * s);
-#define OISAT_MFMA4(c)                                                                          \
-    acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.c, b0.c, acc00, 0, 0, 0);                   \
-    acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.c, b1.c, acc01, 0, 0, 0);                   \
-    acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.c, b0.c, acc10, 0, 0, 0);                   \
-    acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.c, b1.c, acc11, 0, 0, 0);
-            OISAT_MFMA4(x) OISAT_MFMA4(y) OISAT_MFMA4(z) OISAT_MFMA4(w)
-        }
-        if (kt + 1 < nkt) OISAT_LSTORE(cur ^ 1);
-        __syncthreads();
+        const bool more = kt + 1 < nkt;
+        if (more) OISAT_GLOAD((kt + 1) * BK);
+        OISAT_FRAG(ga0, ga1, gb0, gb1, cur, 1);
+        OISAT_MFMA16(fa0, fa1, fb0, fb1)                       // s = 0
+        OISAT_FRAG(fa0, fa1, fb0, fb1, cur, 2);
+        OISAT_MFMA16(ga0, ga1, gb0, gb1)                       // s = 1
+        if (more) OISAT_LSTORE(cur ^ 1);                        // other buffer is free since the last barrier
+        OISAT_FRAG(ga0, ga1, gb0, gb1, cur, 3);
+        OISAT_MFMA16(fa0, fa1, fb0, fb1)                       // s = 2
+        __syncthreads();                                        // tile kt+1 visible; every read of tile kt has been issued
+        if (more) OISAT_FRAG(fa0, fa1, fb0, fb1, cur ^ 1, 0);   // first operands of the next tile, behind the last MFMA group
+        OISAT_MFMA16(ga0, ga1, gb0, gb1)                       // s = 3
     }
     // epilogue: C/D layout col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
     float* Cg = C + ((int64_t)ti * NB + wr * 64) * ldc + (int64_t)tj * NB + wc * 64;
