@@ -174,6 +174,42 @@ def tiled_leg(ctx, workload, sync):
             "solve_tflops_end_to_end": ta.flops / (el / 3) / 1e12}
 
 
+def regrid_leg(ctx, sync):
+    """One OMI-NO2-like granule (1644 x 60 pixels, 35 scattering-weight + 35 pressure levels, vcd, amf,
+    uncertainty = 73 fields) regridded onto a 0.25 deg global model grid through the drop-in
+    interpolator() (host arrays in, host arrays out), nearest-neighbour type 4 and Delaunay type 1.
+    The reference does one k-d tree build + query and one evaluation PER FIELD (interpolator.py:162-209)."""
+    from oisatgmi import synthetic as syn
+    from oisatgmi.interpolator import interpolator, _plan_cache
+    from oracle import oi_oracle as orc
+    g = syn.swath_granule(7007, nscan=1644, npix=60, lat0=-70.0, lat1=70.0, lon_c=20.0, width_deg=24.0)
+    nz = 35
+    rng = np.random.default_rng(5)
+    g.scattering_weights = rng.uniform(0.1, 2.0, size=(nz,) + g.vcd.shape).astype(np.float32)
+    g.pressure_mid = rng.uniform(50, 1000, size=(nz,) + g.vcd.shape).astype(np.float32)
+    ctm = syn.regional_ctm_grid(-89.875, 89.875, -179.875, 179.875, 0.25, 0.25)
+    out = {"workload": "interpolator(): 98,640-pixel granule, 73 fields -> 0.25 deg global grid (720x1440), float64, host in/out"}
+    import contextlib, io
+    for it in (4, 1):
+        _plan_cache.clear()
+        with contextlib.redirect_stdout(io.StringIO()):
+            interpolator(it, 0.25, g, ctm, 0.75)                      # warm-up (allocations, plan cache)
+            sync()
+            t0 = time.perf_counter()
+            r = interpolator(it, 0.25, g, ctm, 0.75)
+            sync()
+        dt = time.perf_counter() - t0
+        out[f"type{it}_s_per_granule"] = dt
+        out[f"type{it}_fields_per_s"] = 73 / dt
+    # the oracle (same algorithm as the reference: cKDTree per field) on ONE field, for scale
+    one = type(g)(g.vcd, g.amf, g.time, g.tropopause, g.latitude_center, g.longitude_center, [], [], g.uncertainty,
+                  g.quality_flag, np.empty((1)), np.empty((1)), False, [], [], [], [])
+    t0 = time.perf_counter()
+    orc.interpolator(4, 0.25, one, ctm, 0.75, record_type=type(g))
+    out["cpu_oracle_s_for_3_fields_type4"] = time.perf_counter() - t0
+    return out
+
+
 def cpu_baseline(workload):
     """Time the float64 oracle (oracle/oi_oracle.py dense_oi: NumPy + SciPy Cholesky) on a bounded
     sample of the workload -- the first `m_s` observations and a random subset of grid cells that
@@ -295,6 +331,7 @@ def main():
         if not args.no_secondary:
             out["tiled"] = tiled_leg(ctx, args.workload, sync)
             out["tier_a"] = tier_a_leg(ctx, ny, nx, nobs, sync)
+            out["regrid"] = regrid_leg(ctx, sync)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)
     if rank == 0:

@@ -235,6 +235,79 @@ def test_averaging_large_stack_against_oracle(ctx):
         np.testing.assert_allclose(a, b, rtol=RT64, equal_nan=True)
 
 
+def test_averaging_edge_cases(ctx):
+    """ragged / degenerate stacks: one granule, odd cell counts (scalar kernel path), float32 granules,
+    cells never observed, a month with a single valid record among Nones."""
+    rng = np.random.default_rng(17)
+    for (ny, nx, k) in ((1, 1, 1), (3, 5, 2), (7, 9, 1), (33, 31, 6)):
+        r = _Reader()
+        r.sat_data = syn.granule_stack(ny, nx, k, 100 + ny, with_none=(k > 1), coverage=0.5) if ny * nx > 8 else None
+        if r.sat_data is None:
+            lat, lon = np.zeros((ny, nx)), np.zeros((ny, nx))
+            import datetime
+            t = datetime.datetime(2019, 6, 3, 12)
+            r.sat_data = [None, cfg.satellite_amf(np.full((ny, nx), 2.0), np.empty(1), t, np.empty(1), lat, lon, [], [],
+                                                  np.full((ny, nx), 0.5), [], np.empty(1), np.empty(1), False,
+                                                  np.full((ny, nx), 3.0), t, np.full((ny, nx), 1.0), np.full((ny, nx), 1.5)), None]
+        res = averaging("2019-06-01", "2019-07-01", r)
+        ref = orc.averaging("2019-06-01", "2019-07-01", r, amf_type=cfg.satellite_amf, opt_type=cfg.satellite_opt)
+        for a, b in zip(res[:5], ref[:5]):
+            np.testing.assert_allclose(a, b, rtol=RT64, equal_nan=True)
+    # float32 granules are reduced in float32, like np.nanmean of a float32 stack
+    r = _Reader()
+    r.sat_data = syn.granule_stack(24, 40, 7, 555)
+    for g in r.sat_data:
+        if g is not None:
+            for f in ("vcd", "uncertainty", "ctm_vcd", "new_amf", "old_amf"):
+                setattr(g, f, getattr(g, f).astype(np.float32))
+    res = averaging("2019-06-01", "2019-07-01", r)
+    ref = orc.averaging("2019-06-01", "2019-07-01", r, amf_type=cfg.satellite_amf, opt_type=cfg.satellite_opt)
+    for a, b in zip(res[:5], ref[:5]):
+        np.testing.assert_allclose(a, b, rtol=RT32, equal_nan=True)
+    # error_averager: k = 1, k = 450 (an OMI month of orbits), all-NaN, all-inf
+    e = rng.uniform(0.01, 1, size=(450, 9, 11))
+    e[rng.uniform(size=e.shape) < 0.7] = np.nan
+    e[:, 0, 0] = np.nan
+    e[:, 1, 1] = np.inf
+    np.testing.assert_allclose(error_averager(e), orc.error_averager(e), rtol=RT64, equal_nan=True)
+    np.testing.assert_allclose(error_averager(e[:1]), orc.error_averager(e[:1]), rtol=RT64, equal_nan=True)
+
+
+def test_averaging_full_size_month(ctx):
+    """720 x 1440 x 30 daily composites (BASELINE grid): against the oracle on the whole field."""
+    r = _Reader()
+    r.sat_data = syn.granule_stack(720, 1440, 30, 3030, with_none=True, coverage=0.25)
+    res = averaging("2019-06-01", "2019-07-01", r)
+    ref = orc.averaging("2019-06-01", "2019-07-01", r, amf_type=cfg.satellite_amf, opt_type=cfg.satellite_opt)
+    for a, b, nm in zip(res[:5], ref[:5], ("sat_vcd", "sat_err", "ctm_vcd", "aux1", "aux2")):
+        np.testing.assert_allclose(a, b, rtol=RT64, equal_nan=True, err_msg=nm)
+    assert res[0].shape == (720, 1440) and np.isnan(res[0]).any() and np.isfinite(res[0]).any()
+
+
+def test_regrid_edge_cases(ctx):
+    """granules that the readers really produce: everything flagged bad, NaN geolocation, a single scan line."""
+    ctm = syn.regional_ctm_grid(-30.0, 50.0, -25.0, 45.0, 2.0, 2.5)
+    s = syn.swath_granule(31)
+    s.quality_flag[:] = 0.1                                     # all values masked -> "doesn't fall into the region"
+    assert interpolator(4, 0.25, s, ctm, 0.75) is None
+    s = syn.swath_granule(32)
+    s.latitude_center[5:9, :] = np.nan                          # pixels without geolocation can never be neighbours
+    s.longitude_center[5:9, :] = np.nan
+    r = interpolator(4, 0.25, s, ctm, 0.75)
+    rows = np.r_[0:5, 9:s.vcd.shape[0]]                          # the same granule without those scan lines
+    clean = cfg.satellite_amf(s.vcd[rows], s.amf[rows], s.time, np.empty(1), s.latitude_center[rows], s.longitude_center[rows],
+                              [], [], s.uncertainty[rows], s.quality_flag[rows], np.empty(1), np.empty(1), False, [], [], [], [])
+    o = orc.interpolator(4, 0.25, clean, ctm, 0.75, record_type=cfg.satellite_amf)
+    for f in ("vcd", "amf", "uncertainty"):
+        np.testing.assert_allclose(getattr(r, f), getattr(o, f), rtol=RT64, equal_nan=True)
+    s = syn.swath_granule(33, nscan=1, npix=200, lat0=10.0, lat1=10.0)
+    r = interpolator(2, 0.25, s, ctm, 0.75)
+    o = orc.interpolator(2, 0.25, s, ctm, 0.75, record_type=cfg.satellite_amf)
+    assert (r is None) == (o is None)
+    if r is not None:
+        np.testing.assert_allclose(r.vcd, o.vcd, rtol=RT64, equal_nan=True)
+
+
 def test_driver_methods(ctx, golden):
     g = golden("averaging_72x144_k5.npz")
     o = oisatgmi()
