@@ -153,7 +153,7 @@ def tier_a_leg(ctx, ny, nx, nobs, sync):
     return {"workload": f"OI(regularization_on=True) {ny}x{nx}, {nobs} observed cells, fp32, device-resident",
             "value": n * 50 / el, "unit": "grid-cells/s", "ms_per_call": 1e3 * el / 50,
             "ms_per_call_with_host_knee_pick": 1e3 * el_host / 20, "knee_index": int(idx),
-            "kernel_ms": {"oi_curve(99 scalings)": curve_ms, "oi_apply": apply_ms},
+            "kernel_ms": {k: v["total_ms"] / v["launches"] for k, v in prof.items()},
             "roofline_oi_apply": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes": DiagOI.algorithmic_bytes(n, 4)}}
 

@@ -73,10 +73,22 @@ __global__ __launch_bounds__(kCurveThreads) void oi_curve_kernel(const T* __rest
             }
         }
     }
-    part_sum[wave * OISAT_MAX_SCALES + lane] = has0 ? acc0 : 0.0;
-    part_sum[wave * OISAT_MAX_SCALES + kWave + lane] = has1 ? acc1 : 0.0;
-    part_cnt[wave * OISAT_MAX_SCALES + lane] = has0 ? c0 : 0u;
-    part_cnt[wave * OISAT_MAX_SCALES + kWave + lane] = has1 ? c1 : 0u;
+    // the block's four waves are combined here in wave order (fixed => reproducible): one partial per block
+    __shared__ double bs[kCurveThreads / kWave][OISAT_MAX_SCALES];
+    __shared__ unsigned bc[kCurveThreads / kWave][OISAT_MAX_SCALES];
+    const int wv = threadIdx.x >> 6;
+    bs[wv][lane] = has0 ? acc0 : 0.0;
+    bs[wv][kWave + lane] = has1 ? acc1 : 0.0;
+    bc[wv][lane] = has0 ? c0 : 0u;
+    bc[wv][kWave + lane] = has1 ? c1 : 0u;
+    __syncthreads();
+    if (threadIdx.x < OISAT_MAX_SCALES) {
+        double S = bs[0][threadIdx.x];
+        unsigned Cn = bc[0][threadIdx.x];
+        for (int k = 1; k < kCurveThreads / kWave; ++k) { S += bs[k][threadIdx.x]; Cn += bc[k][threadIdx.x]; }
+        part_sum[(int64_t)blockIdx.x * OISAT_MAX_SCALES + threadIdx.x] = S;
+        part_cnt[(int64_t)blockIdx.x * OISAT_MAX_SCALES + threadIdx.x] = Cn;
+    }
 }
 
 // NumPy's pairwise summation for n < 128 (8 running sums, then the remainder), so that the device
@@ -99,33 +111,47 @@ __device__ double numpy_sum_small(const double* a, int n) {
 
 // Kneedle for an increasing concave curve -- the device twin of oisatgmi/_kneedle.py (itself a
 // restatement of kneed.KneeLocator(x, y, direction='increasing').knee, optimal_interpolation.py:37-39).
-// Single thread, 99 points.  Returns -1 when no knee is found (the caller falls back to index 0, :40-41).
-__device__ int kneedle_index(const double* x, const double* y, int n, double* w /* 4*n doubles of scratch */) {
-    if (n < 3) return -1;
+// One workgroup of OISAT_MAX_SCALES threads: the element-wise steps (99 points) run one point per
+// thread, the min/max, the NumPy-ordered mean and the threshold walk on thread 0.
+// Returns -1 when no knee is found (the caller falls back to index 0, :40-41).
+__device__ int kneedle_index_block(const double* x, const double* y, int n, double* w /* 4*n doubles of LDS */, int tid) {
     double* ds = w;            // interp1d(x, y)(x): left segment evaluated at the node
     double* xn = w + n;
     double* df = w + 2 * n;    // difference curve
     double* dx = w + 3 * n;
-    ds[0] = y[0];
-    for (int i = 1; i < n; ++i) {
-        const double slope = (y[i] - y[i - 1]) / (x[i] - x[i - 1]);
-        ds[i] = slope * (x[i] - x[i - 1]) + y[i - 1];
+    __shared__ double mm[4];
+    __shared__ int s_flag;
+    if (tid < n) {
+        if (tid == 0) ds[0] = y[0];
+        else {
+            const double slope = (y[tid] - y[tid - 1]) / (x[tid] - x[tid - 1]);
+            ds[tid] = slope * (x[tid] - x[tid - 1]) + y[tid - 1];
+        }
     }
-    double xmin = x[0], xmax = x[0], ymin = ds[0], ymax = ds[0];
-    bool ynan = ds[0] != ds[0];
-    for (int i = 1; i < n; ++i) {
-        xmin = x[i] < xmin ? x[i] : xmin;
-        xmax = x[i] > xmax ? x[i] : xmax;
-        if (ds[i] != ds[i]) ynan = true;
-        ymin = ds[i] < ymin ? ds[i] : ymin;
-        ymax = ds[i] > ymax ? ds[i] : ymax;
+    __syncthreads();
+    if (tid == 0) {
+        double xmin = x[0], xmax = x[0], ymin = ds[0], ymax = ds[0];
+        bool ynan = ds[0] != ds[0];
+        for (int i = 1; i < n; ++i) {
+            xmin = x[i] < xmin ? x[i] : xmin;
+            xmax = x[i] > xmax ? x[i] : xmax;
+            if (ds[i] != ds[i]) ynan = true;
+            ymin = ds[i] < ymin ? ds[i] : ymin;
+            ymax = ds[i] > ymax ? ds[i] : ymax;
+        }
+        mm[0] = xmin; mm[1] = xmax; mm[2] = ymin; mm[3] = ymax;
+        s_flag = (ynan || n < 3) ? 1 : 0;      // np.min/np.max propagate NaN -> every comparison below is False
     }
-    if (ynan) return -1;       // np.min/np.max propagate NaN -> every comparison below is False
-    for (int i = 0; i < n; ++i) {
-        xn[i] = (x[i] - xmin) / (xmax - xmin);
-        df[i] = (ds[i] - ymin) / (ymax - ymin) - xn[i];
+    __syncthreads();
+    if (s_flag) return -1;
+    if (tid < n) {
+        xn[tid] = (x[tid] - mm[0]) / (mm[1] - mm[0]);
+        df[tid] = (ds[tid] - mm[2]) / (mm[3] - mm[2]) - xn[tid];
     }
-    for (int i = 0; i + 1 < n; ++i) dx[i] = xn[i + 1] - xn[i];
+    __syncthreads();
+    if (tid + 1 < n) dx[tid] = xn[tid + 1] - xn[tid];
+    __syncthreads();
+    if (tid != 0) return -1;                   // (only thread 0's return value is used)
     const double step = fabs(numpy_sum_small(dx, n - 1) / (double)(n - 1));
     // walk: thresholds reset at every local maximum (>= both neighbours, ends clipped), 0 at every local minimum
     int first = -1;
@@ -146,48 +172,48 @@ __device__ int kneedle_index(const double* x, const double* y, int n, double* w 
     return -1;
 }
 
-// one block of 1024 threads = 128 scales x 8 slices of the per-wave partials, combined in slice order
-// (fixed order => bitwise reproducible); thread 0 then optionally picks the knee on the device.
-__global__ __launch_bounds__(1024) void oi_curve_finish_kernel(const double* __restrict__ part_sum,
-                                                                const unsigned* __restrict__ part_cnt, int nscales,
-                                                                const double* __restrict__ scales, double* __restrict__ mean_out,
-                                                                long long* __restrict__ cnt_out, int pick_knee, int forced_index,
-                                                                int* __restrict__ index_out) {
-    __shared__ double ssum[8][OISAT_MAX_SCALES];
-    __shared__ long long scnt[8][OISAT_MAX_SCALES];
-    __shared__ double scratch[4 * OISAT_MAX_SCALES];
-    __shared__ double smean[OISAT_MAX_SCALES], sx[OISAT_MAX_SCALES];
-    const int t = threadIdx.x & (OISAT_MAX_SCALES - 1), sl = threadIdx.x >> 7;
-    constexpr int per = kCurveWaves / 8;
+// one block per scaling: 256 threads add the kCurveBlocks block partials (thread j takes j, j+256, ...),
+// then a fixed binary tree in LDS -- same order every run => bitwise reproducible means
+__global__ __launch_bounds__(256) void oi_curve_finish_kernel(const double* __restrict__ part_sum,
+                                                               const unsigned* __restrict__ part_cnt,
+                                                               double* __restrict__ mean_out, long long* __restrict__ cnt_out) {
+    __shared__ double ss[256];
+    __shared__ long long sc[256];
+    const int t = blockIdx.x, j = threadIdx.x;
     double s = 0.0;
     long long c = 0;
-    for (int w = sl * per; w < (sl + 1) * per; ++w) {
-        s += part_sum[(int64_t)w * OISAT_MAX_SCALES + t];
-        c += part_cnt[(int64_t)w * OISAT_MAX_SCALES + t];
+#pragma unroll
+    for (int k = 0; k < kCurveBlocks / 256; ++k) {
+        s += part_sum[(int64_t)(j + 256 * k) * OISAT_MAX_SCALES + t];
+        c += part_cnt[(int64_t)(j + 256 * k) * OISAT_MAX_SCALES + t];
     }
-    ssum[sl][t] = s;
-    scnt[sl][t] = c;
+    ss[j] = s;
+    sc[j] = c;
     __syncthreads();
-    if (sl == 0 && t < nscales) {
-        double S = ssum[0][t];
-        long long Cn = scnt[0][t];
-        for (int k = 1; k < 8; ++k) { S += ssum[k][t]; Cn += scnt[k][t]; }
-        const double mean = S / (double)Cn;      // 0/0 -> NaN like np.nanmean of an all-NaN slice
-        mean_out[t] = mean;
-        cnt_out[t] = Cn;
-        smean[t] = mean;
-        sx[t] = scales[t];
+    for (int h = 128; h > 0; h >>= 1) {
+        if (j < h) { ss[j] += ss[j + h]; sc[j] += sc[j + h]; }
+        __syncthreads();
     }
+    if (j == 0) {
+        mean_out[t] = ss[0] / (double)sc[0];      // 0/0 -> NaN like np.nanmean of an all-NaN slice
+        cnt_out[t] = sc[0];
+    }
+}
+
+// the knee pick on the device (one thread; 99 numbers)
+__global__ void oi_knee_kernel(const double* __restrict__ scales, const double* __restrict__ mean, int nscales, int pick_knee,
+                               int forced_index, int* __restrict__ index_out) {
+    __shared__ double scratch[4 * OISAT_MAX_SCALES];
+    __shared__ double smean[OISAT_MAX_SCALES], sx[OISAT_MAX_SCALES];
+    if (threadIdx.x < nscales) { smean[threadIdx.x] = mean[threadIdx.x]; sx[threadIdx.x] = scales[threadIdx.x]; }
     __syncthreads();
-    if (threadIdx.x == 0 && index_out) {
-        int idx = 0;
-        if (forced_index >= 0) idx = forced_index;
-        else if (pick_knee) {
-            const int k = kneedle_index(sx, smean, nscales, scratch);
-            idx = k < 0 ? 0 : k;
-        }
-        *index_out = idx;
+    int idx = 0;
+    if (forced_index >= 0) idx = forced_index;
+    else if (pick_knee) {                       // block-uniform branch: every thread takes part
+        const int k = kneedle_index_block(sx, smean, nscales, scratch, threadIdx.x);
+        idx = k < 0 ? 0 : k;
     }
+    if (threadIdx.x == 0) *index_out = idx;
 }
 
 template <typename T>
@@ -239,8 +265,8 @@ struct CurveWs {
     char* ws;
     static constexpr size_t off_scales = 0;
     static constexpr size_t off_psum = 1024;
-    static constexpr size_t off_pcnt = off_psum + sizeof(double) * kCurveWaves * OISAT_MAX_SCALES;
-    static constexpr size_t off_mean = off_pcnt + sizeof(unsigned) * kCurveWaves * OISAT_MAX_SCALES;
+    static constexpr size_t off_pcnt = off_psum + sizeof(double) * kCurveBlocks * OISAT_MAX_SCALES;
+    static constexpr size_t off_mean = off_pcnt + sizeof(unsigned) * kCurveBlocks * OISAT_MAX_SCALES;
     static constexpr size_t off_cnt = off_mean + sizeof(double) * OISAT_MAX_SCALES;
     static constexpr size_t off_idx = off_cnt + sizeof(long long) * OISAT_MAX_SCALES;
     static constexpr size_t total = off_idx + 64;
@@ -268,10 +294,13 @@ int curve_enqueue(oisat_ctx* h, const T* Sa, const T* So, int64_t n, const doubl
     OISAT_LAUNCH(h, "oi_curve", (oi_curve_kernel<T>), dim3(kCurveBlocks), dim3(kCurveThreads), 0, Sa, So, n,
                  (const double*)(cw.ws + CurveWs::off_scales), nscales, (double*)(cw.ws + CurveWs::off_psum),
                  (unsigned*)(cw.ws + CurveWs::off_pcnt));
-    OISAT_LAUNCH(h, "oi_curve_finish", oi_curve_finish_kernel, dim3(1), dim3(1024), 0, (const double*)(cw.ws + CurveWs::off_psum),
-                 (const unsigned*)(cw.ws + CurveWs::off_pcnt), nscales, (const double*)(cw.ws + CurveWs::off_scales),
-                 (double*)(cw.ws + CurveWs::off_mean), (long long*)(cw.ws + CurveWs::off_cnt), pick_knee, forced_index,
-                 (int*)(cw.ws + CurveWs::off_idx));
+    OISAT_LAUNCH(h, "oi_curve_finish", oi_curve_finish_kernel, dim3(nscales), dim3(256), 0, (const double*)(cw.ws + CurveWs::off_psum),
+                 (const unsigned*)(cw.ws + CurveWs::off_pcnt), (double*)(cw.ws + CurveWs::off_mean),
+                 (long long*)(cw.ws + CurveWs::off_cnt));
+    if (pick_knee || forced_index >= 0) {
+        OISAT_LAUNCH(h, "oi_knee", oi_knee_kernel, dim3(1), dim3(OISAT_MAX_SCALES), 0, (const double*)(cw.ws + CurveWs::off_scales),
+                     (const double*)(cw.ws + CurveWs::off_mean), nscales, pick_knee, forced_index, (int*)(cw.ws + CurveWs::off_idx));
+    }
     return OISAT_OK;
 }
 
