@@ -104,6 +104,10 @@ int oisat_affine(oisat_ctx* h, int dtype, const void* x, int64_t n, double offse
 int oisat_oi_variances(oisat_ctx* h, int dtype, const void* Xa, const void* sat_err, int64_t n,
                        double error_ctm, void* Sa_out, void* So_out);
 
+/* Emission scaling factor written to the output file: posterior/prior with NaN, +/-inf and 0 mapped to 1.0
+ * (write_to_nc, driver.py:204-206). */
+int oisat_scaling_factor(oisat_ctx* h, int dtype, const void* posterior, const void* prior, int64_t n, void* out);
+
 /* ---- regridding: interpolator.py:10-97 --------------------------------------------------------- */
 /* signal.convolve2d(Z, ones(ky,kx)/(kx*ky)^(1|2), boundary='symm', mode='same'),
  * interpolator.py:40-46,:72-76.  Z, out: dev Ny*Nx row-major.  variance != 0 -> /(kx*ky)^2. */

@@ -249,6 +249,17 @@ __global__ __launch_bounds__(256) void affine_kernel(const T* __restrict__ x, in
 }
 
 template <typename T>
+__global__ __launch_bounds__(256) void scaling_factor_kernel(const T* __restrict__ post, const T* __restrict__ prior, int64_t n,
+                                                              T* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const T r = post[i] / prior[i];
+        const bool bad = (r != r) || r == __builtin_inf() || r == -__builtin_inf() || r == T(0);
+        out[i] = bad ? T(1) : r;                 // driver.py:204-206
+    }
+}
+
+template <typename T>
 __global__ __launch_bounds__(256) void variances_kernel(const T* __restrict__ xa, const T* __restrict__ e, int64_t n, T pct,
                                                          T* __restrict__ Sa, T* __restrict__ So) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -406,6 +417,20 @@ extern "C" int oisat_oi_variances(oisat_ctx* h, int dtype, const void* Xa, const
     } else {
         OISAT_LAUNCH(h, "oi_variances", (variances_kernel<double>), dim3(grid), dim3(256), 0, (const double*)Xa,
                      (const double*)sat_err, n, error_ctm, (double*)Sa_out, (double*)So_out);
+    }
+    return OISAT_OK;
+}
+
+extern "C" int oisat_scaling_factor(oisat_ctx* h, int dtype, const void* posterior, const void* prior, int64_t n, void* out) {
+    ARG_CHECK(h && posterior && prior && out && n > 0);
+    ARG_CHECK(dtype == OISAT_F32 || dtype == OISAT_F64);
+    const int grid = stream_grid(n, 256);
+    if (dtype == OISAT_F32) {
+        OISAT_LAUNCH(h, "scaling_factor", (scaling_factor_kernel<float>), dim3(grid), dim3(256), 0, (const float*)posterior,
+                     (const float*)prior, n, (float*)out);
+    } else {
+        OISAT_LAUNCH(h, "scaling_factor", (scaling_factor_kernel<double>), dim3(grid), dim3(256), 0, (const double*)posterior,
+                     (const double*)prior, n, (double*)out);
     }
     return OISAT_OK;
 }

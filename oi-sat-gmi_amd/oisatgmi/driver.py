@@ -3,8 +3,9 @@
 Drop-in for the three methods of ``oisatgmi/driver.py`` that lie on the optimal-interpolation
 path: ``average`` (:53-63), ``bias_correct`` (:65-106) and ``oi`` (:108-114), with the same
 attribute names set on ``self``.  The I/O methods of the reference's class (``read_data``,
-``recal_amf``, ``cal_pwv``, ``conv_ak``, ``reporting``, ``savedaily``, ``write_to_nc``) are file
-formats, plotting and sensor-specific operators outside this path:
+``recal_amf``, ``cal_pwv``, ``conv_ak``, ``reporting``, ``savedaily``) are file
+formats, plotting and sensor-specific operators outside this path; ``write_to_nc`` (the output stage,
+SURVEY.md section 8(f) row 4) is kept: same variables, with the scaling-factor rule evaluated on the device:
 they raise ``NotImplementedError`` here -- see INTEGRATION.md for binding the HIP path into the
 reference's own class instead.
 """
@@ -12,6 +13,9 @@ from __future__ import annotations
 
 import numpy as np
 
+import os
+
+from . import _hip
 from .averaging import averaging
 from .optimal_interpolation import OI
 
@@ -63,6 +67,74 @@ class oisatgmi(object):
         self.ctm_averaged_vcd_corrected, self.ak_OI, self.increment_OI, self.error_OI = OI(
             xa, y, (xa * error_ctm / 100.0) ** 2, self.sat_averaged_error ** 2, regularization_on=True)
 
+    def scaling_factor(self):
+        """posterior / prior model column with NaN, inf and 0 mapped to 1.0 -- the field the downstream
+        emission tools consume (write_to_nc, driver.py:204-206); evaluated on the device."""
+        post = np.ascontiguousarray(self.ctm_averaged_vcd_corrected)
+        prior = np.ascontiguousarray(self.ctm_averaged_vcd)
+        ctx = _hip.context()
+        dt = _hip.compute_dtype(post, prior)
+        n = int(post.size)
+        buf = ctx.alloc(3 * n * dt.itemsize)
+        ctx.upload_into(buf.at(0), post, dtype=dt)
+        ctx.upload_into(buf.at(n * dt.itemsize), prior, dtype=dt)
+        ctx.check(ctx.lib.oisat_scaling_factor(ctx.h, _hip.dtype_code(dt), buf.at(0), buf.at(n * dt.itemsize), n,
+                                               buf.at(2 * n * dt.itemsize)))
+        return ctx.download(buf.at(2 * n * dt.itemsize), post.shape, dt)
+
+    def output_fields(self):
+        """The variables of the reference's output file, in its order and as float32 (driver.py:179-225)."""
+        first = next(g for g in self.reader_obj.sat_data if g is not None)
+        f32 = lambda a: np.asarray(a, dtype=np.float32)       # noqa: E731
+        return {
+            "sat_averaged_vcd": f32(self.sat_averaged_vcd), "ctm_averaged_vcd_prior": f32(self.ctm_averaged_vcd),
+            "ctm_averaged_vcd_posterior": f32(self.ctm_averaged_vcd_corrected), "sat_averaged_error": f32(self.sat_averaged_error),
+            "ak_OI": f32(self.ak_OI), "error_OI": f32(self.error_OI), "scaling_factor": f32(self.scaling_factor()),
+            "lon": f32(first.longitude_center), "lat": f32(first.latitude_center), "aux1": f32(self.aux1), "aux2": f32(self.aux2),
+        }
+
+    def write_to_nc(self, output_file, output_folder='diag'):
+        '''
+        Write the final results to a netcdf (same variable names, types and dimensions as the reference,
+        driver.py:156-227).  Uses netCDF4 when it is installed; otherwise SciPy's NetCDF-3 writer.
+        ARGS:
+            output_file (char): the name of file to be outputted
+        '''
+        if not os.path.exists(output_folder):
+            os.makedirs(output_folder)
+        fields = self.output_fields()
+        path = output_folder + '/' + output_file + '.nc'
+        time_string = self.avg_time.strftime("%Y-%m-%d %H:%M:%S")
+        nx_, ny_ = np.shape(self.sat_averaged_vcd)[0], np.shape(self.sat_averaged_vcd)[1]
+        try:
+            from netCDF4 import Dataset
+        except ImportError:
+            Dataset = None
+        if Dataset is not None:
+            nc = Dataset(path, 'w')
+            nc.createDimension('x', nx_)
+            nc.createDimension('y', ny_)
+            nc.createDimension('t', None)
+            tv = nc.createVariable('time', 'S1', ('t'))
+            tv[:] = np.array(list(time_string), 'S1')
+            for name, arr in fields.items():
+                v = nc.createVariable(name, 'f4', ('x', 'y'))
+                v[:, :] = arr
+            nc.close()
+        else:
+            from scipy.io import netcdf_file
+            nc = netcdf_file(path, 'w')
+            nc.createDimension('x', nx_)
+            nc.createDimension('y', ny_)
+            nc.createDimension('t', len(time_string))       # NetCDF-3 via SciPy: fixed length instead of unlimited
+            tv = nc.createVariable('time', 'c', ('t',))
+            tv[:] = np.array(list(time_string), 'S1')
+            for name, arr in fields.items():
+                v = nc.createVariable(name, 'f', ('x', 'y'))
+                v[:, :] = arr
+            nc.close()
+        return path
+
     # ---- outside the hot path ---------------------------------------------------------------
     def _out_of_scope(self, name):
         raise NotImplementedError(
@@ -88,5 +160,3 @@ class oisatgmi(object):
     def savedaily(self, *a, **k):
         self._out_of_scope("savedaily")
 
-    def write_to_nc(self, *a, **k):
-        self._out_of_scope("write_to_nc")

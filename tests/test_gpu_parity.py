@@ -335,7 +335,27 @@ def test_driver_methods(ctx, golden):
     ref = orc.OI(Xa.copy(), Y, Sa, So, regularization_on=True)
     np.testing.assert_allclose(o2.ctm_averaged_vcd_corrected, ref[0], rtol=RT64, equal_nan=True)
     with pytest.raises(NotImplementedError):
-        o.write_to_nc("x", "y")
+        o.reporting("x", "NO2")
+    # output stage (driver.py:156-227): scaling-factor rule NaN/inf/0 -> 1 and the variable list
+    post, prior = o.ctm_averaged_vcd_corrected.copy(), o.ctm_averaged_vcd.copy()
+    obs = np.argwhere(np.isfinite(post))
+    o.ctm_averaged_vcd_corrected[tuple(obs[0])] = 0.0                     # exact 0 -> 1
+    o.ctm_averaged_vcd[tuple(obs[1])] = 0.0                               # x/0 = inf -> 1
+    with np.errstate(all="ignore"):
+        want = o.ctm_averaged_vcd_corrected / o.ctm_averaged_vcd
+    want[np.isnan(want) | np.isinf(want) | (want == 0.0)] = 1.0
+    np.testing.assert_array_equal(o.scaling_factor(), want)
+    import tempfile
+    from scipy.io import netcdf_file
+    with tempfile.TemporaryDirectory() as td:
+        path = o.write_to_nc("NO2_201906", td)
+        nc = netcdf_file(path, "r", mmap=False)
+        assert set(nc.variables) == {"time", "sat_averaged_vcd", "ctm_averaged_vcd_prior", "ctm_averaged_vcd_posterior",
+                                     "sat_averaged_error", "ak_OI", "error_OI", "scaling_factor", "lon", "lat", "aux1", "aux2"}
+        np.testing.assert_array_equal(nc.variables["scaling_factor"][:], want.astype(np.float32))
+        assert nc.variables["ak_OI"][:].dtype.itemsize == 4 and nc.variables["lat"].shape == post.shape
+        assert b"".join(nc.variables["time"][:]).decode().startswith("2019-06")
+        nc.close()
 
 
 # ------------------------------------------------------------------------------------------------
