@@ -108,6 +108,26 @@ int oisat_oi_variances(oisat_ctx* h, int dtype, const void* Xa, const void* sat_
  * (write_to_nc, driver.py:204-206). */
 int oisat_scaling_factor(oisat_ctx* h, int dtype, const void* posterior, const void* prior, int64_t n, void* out);
 
+/* ---- AMF recalculation (upstream of the averaging): amf_recal.py ---------------------------------------- */
+/* Model partial column deltap*profile/g/Mair*N_A*1e-4*1e-15*100*1e-9, left to right in `dtype` (:51-56). */
+int oisat_partial_column(oisat_ctx* h, int dtype, const void* deltap, const void* profile, int64_t n, void* out);
+
+/* Per-pixel vertical interpolation and AMF (the Python double loop :93-119 plus the record update :176-182):
+ * scattering weights interpolated in log-pressure onto the model levels (scipy interp1d, linear,
+ * fill_value="extrapolate": stable sort, searchsorted-left, clipped end segments), inf -> 0, tropopause
+ * mask, model SCD / VCD by nansum in NumPy's pairwise order, new AMF = SCD/VCD (NaN if VCD == 0),
+ * vcd_out = amf*vcd/new_amf, ctm_vcd = model VCD (NaN where vcd_out is NaN/inf).
+ * Cubes are level-major [nz][n]; satellite cubes double, model cubes of ctm_dtype (np.log and the VCD
+ * nansum are evaluated in that dtype, as NumPy does); nzs <= 64, nzc <= 128; tropopause may be NULL. */
+int oisat_amf_recal(oisat_ctx* h, const double* sat_pmid, const double* sat_sw, int nzs, int ctm_dtype,
+                    const void* ctm_pmid, const void* ctm_partial, int nzc, const double* tropopause, const double* vcd,
+                    const double* amf, int64_t n, double* new_amf, double* vcd_out, double* ctm_vcd);
+
+/* No scattering weights (:160-171): ctm_vcd = nansum over levels of the partial columns (levels with
+ * p < tropopause dropped when tropopause != NULL), NaN where vcd is NaN; cube and output in `dtype`. */
+int oisat_column_sum(oisat_ctx* h, int dtype, const void* ctm_pmid, const void* ctm_partial, int nzc,
+                     const double* tropopause, const double* vcd, int64_t n, void* ctm_vcd);
+
 /* ---- regridding: interpolator.py:10-97 --------------------------------------------------------- */
 /* signal.convolve2d(Z, ones(ky,kx)/(kx*ky)^(1|2), boundary='symm', mode='same'),
  * interpolator.py:40-46,:72-76.  Z, out: dev Ny*Nx row-major.  variance != 0 -> /(kx*ky)^2. */

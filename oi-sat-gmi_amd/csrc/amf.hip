@@ -1,0 +1,186 @@
+// AMF recalculation, the step immediately upstream of the monthly averaging
+// (amf_recal.py:51-56, :85-119 and :160-183 of the reference).
+//
+// The reference walks every pixel in a Python double loop and builds a scipy interp1d object per
+// pixel (:97-119).  Here a thread owns a pixel: its scattering-weight profile is sorted by
+// log-pressure in thread-private memory (interp1d sorts with a stable argsort), every model level is
+// located by binary search and interpolated / extrapolated with the operation order of scipy's
+// _call_linear, and the two column sums are taken in NumPy's pairwise order, so float64 results
+// agree with the reference to the last bits.
+//
+// HBM layout: level-major cubes [nz][ny*nx] (what the readers and interpolator() produce), so for
+// each level a wave reads 64 consecutive pixels: coalesced.  Everything is double.
+#include "oisat_common.h"
+
+namespace {
+
+constexpr int kMaxSat = 64;      // satellite levels (OMI NO2: 35)
+constexpr int kMaxCtm = 128;     // model levels (GMI: 72)
+
+// (deltap * profile / g / Mair * N_A * 1e-4 * 1e-15 * 100.0 * 1e-9), evaluated left to right in T
+template <typename T>
+__global__ __launch_bounds__(256) void partial_column_kernel(const T* __restrict__ deltap, const T* __restrict__ profile, int64_t n,
+                                                              T* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        T v = deltap[i] * profile[i];
+        v = v / T(9.80665);
+        v = v / T(28.97e-3);
+        v = v * T(6.02214076e23);
+        v = v * T(1e-4);
+        v = v * T(1e-15);
+        v = v * T(100.0);
+        v = v * T(1e-9);
+        out[i] = v;
+    }
+}
+
+// np.sum of n (<= 128) values in NumPy's pairwise order: 8 running sums, then the remainder
+template <typename T>
+__device__ T numpy_sum_le128(const T* a, int n) {
+    if (n < 8) {
+        T r = T(0);
+        for (int i = 0; i < n; ++i) r += a[i];
+        return r;
+    }
+    T r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8) {
+        r0 += a[i]; r1 += a[i + 1]; r2 += a[i + 2]; r3 += a[i + 3];
+        r4 += a[i + 4]; r5 += a[i + 5]; r6 += a[i + 6]; r7 += a[i + 7];
+    }
+    T res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; ++i) res += a[i];
+    return res;
+}
+
+__device__ __forceinline__ bool before(double a, double b) {        // NaN sorts last, like np.argsort
+    if (a != a) return false;
+    if (b != b) return true;
+    return a < b;
+}
+
+// T = dtype of the model cubes.  NumPy keeps it where the reference does: np.log(ctm_p) and
+// np.nansum(partial column) are evaluated in T, everything multiplied by a float64 array is float64.
+template <typename T>
+__global__ __launch_bounds__(128) void amf_recal_kernel(const double* __restrict__ sat_p, const double* __restrict__ sat_sw, int nzs,
+                                                         const T* __restrict__ ctm_p, const T* __restrict__ ctm_pc, int nzc,
+                                                         const double* __restrict__ trop, const double* __restrict__ vcd,
+                                                         const double* __restrict__ amf, int64_t n, double* __restrict__ new_amf,
+                                                         double* __restrict__ vcd_out, double* __restrict__ ctm_vcd) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const double nan = __builtin_nan("");
+    const double v0 = vcd[p];
+    if (v0 != v0) {                       // amf_recal.py:99-100 skips the pixel; :176,:180 leave NaN everywhere
+        new_amf[p] = nan;
+        vcd_out[p] = (amf[p] * v0) / nan;
+        ctm_vcd[p] = nan;
+        return;
+    }
+    double xs[kMaxSat], ys[kMaxSat];
+    for (int k = 0; k < nzs; ++k) {       // stable insertion sort by log-pressure
+        const double x = log(sat_p[(int64_t)k * n + p]), y = sat_sw[(int64_t)k * n + p];
+        int j = k;
+        while (j > 0 && before(x, xs[j - 1])) { xs[j] = xs[j - 1]; ys[j] = ys[j - 1]; --j; }
+        xs[j] = x;
+        ys[j] = y;
+    }
+    double prod[kMaxCtm];
+    T part[kMaxCtm];
+    const bool has_trop = trop != nullptr;
+    const double tp = has_trop ? trop[p] : 0.0;
+    for (int c = 0; c < nzc; ++c) {
+        const T pcT = ctm_p[(int64_t)c * n + p];
+        const double pc = (double)pcT;
+        double col = (double)ctm_pc[(int64_t)c * n + p];
+        const double xq = (double)(T)log(pc);              // correctly rounded log in the model dtype (np.log(float32 array) is float32)
+        int lo = 0, hi = nzs;              // np.searchsorted(xs, xq, 'left'); NaN query -> nzs
+        if (xq != xq) lo = nzs;
+        else
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (before(xs[mid], xq)) lo = mid + 1; else hi = mid;
+            }
+        int idx = lo < 1 ? 1 : (lo > nzs - 1 ? nzs - 1 : lo);
+        const double x_lo = xs[idx - 1], x_hi = xs[idx], y_lo = ys[idx - 1], y_hi = ys[idx];
+        const double slope = (y_hi - y_lo) / (x_hi - x_lo);
+        double sw = slope * (xq - x_lo) + y_lo;
+        if (sw == __builtin_inf() || sw == -__builtin_inf()) sw = 0.0;       // :109
+        if (has_trop && pc < tp) { sw = nan; col = nan; }                     // :111-114
+        const double pr = sw * col;
+        prod[c] = (pr != pr) ? 0.0 : pr;   // np.nansum: NaN -> 0, then np.sum
+        part[c] = (col != col) ? T(0) : (T)col;
+    }
+    const double scd = numpy_sum_le128<double>(prod, nzc);
+    const double mv = (double)numpy_sum_le128<T>(part, nzc);
+    const double a_new = (mv != 0.0) ? scd / mv : nan;                        // :117
+    new_amf[p] = a_new;
+    const double vc = (amf[p] * v0) / a_new;                                  // :179
+    vcd_out[p] = vc;
+    ctm_vcd[p] = (vc != vc || vc == __builtin_inf() || vc == -__builtin_inf()) ? nan : mv;      // :180-181
+}
+
+// no scattering weights: model VCD = nansum over levels of the (tropopause-masked) partial columns, :162-166
+template <typename T>
+__global__ __launch_bounds__(256) void column_sum_kernel(const T* __restrict__ ctm_p, const T* __restrict__ ctm_pc, int nzc,
+                                                          const double* __restrict__ trop, const double* __restrict__ vcd, int64_t n,
+                                                          T* __restrict__ ctm_vcd) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+        T s = T(0);                         // np.nansum(axis=0) in the cube's dtype: level after level
+        for (int c = 0; c < nzc; ++c) {
+            T col = ctm_pc[(int64_t)c * n + p];
+            if (trop && (double)ctm_p[(int64_t)c * n + p] < trop[p]) col = nan_of<T>();
+            if (col == col) s += col;
+        }
+        const double v0 = vcd[p];
+        ctm_vcd[p] = (v0 != v0) ? nan_of<T>() : s;
+    }
+}
+
+}  // namespace
+
+extern "C" int oisat_partial_column(oisat_ctx* h, int dtype, const void* deltap, const void* profile, int64_t n, void* out) {
+    ARG_CHECK(h && deltap && profile && out && n > 0);
+    ARG_CHECK(dtype == OISAT_F32 || dtype == OISAT_F64);
+    const int grid = stream_grid(n, 256);
+    if (dtype == OISAT_F32) {
+        OISAT_LAUNCH(h, "partial_column", (partial_column_kernel<float>), dim3(grid), dim3(256), 0, (const float*)deltap,
+                     (const float*)profile, n, (float*)out);
+    } else {
+        OISAT_LAUNCH(h, "partial_column", (partial_column_kernel<double>), dim3(grid), dim3(256), 0, (const double*)deltap,
+                     (const double*)profile, n, (double*)out);
+    }
+    return OISAT_OK;
+}
+
+extern "C" int oisat_amf_recal(oisat_ctx* h, const double* sat_pmid, const double* sat_sw, int nzs, int ctm_dtype,
+                               const void* ctm_pmid, const void* ctm_partial, int nzc, const double* tropopause, const double* vcd,
+                               const double* amf, int64_t n, double* new_amf, double* vcd_out, double* ctm_vcd) {
+    ARG_CHECK(h && sat_pmid && sat_sw && ctm_pmid && ctm_partial && vcd && amf && new_amf && vcd_out && ctm_vcd && n > 0);
+    ARG_CHECK(nzs >= 2 && nzs <= kMaxSat && nzc >= 1 && nzc <= kMaxCtm);
+    ARG_CHECK(ctm_dtype == OISAT_F32 || ctm_dtype == OISAT_F64);
+    if (ctm_dtype == OISAT_F32) {
+        OISAT_LAUNCH(h, "amf_recal", (amf_recal_kernel<float>), dim3((unsigned)cdiv(n, 128)), dim3(128), 0, sat_pmid, sat_sw, nzs,
+                     (const float*)ctm_pmid, (const float*)ctm_partial, nzc, tropopause, vcd, amf, n, new_amf, vcd_out, ctm_vcd);
+    } else {
+        OISAT_LAUNCH(h, "amf_recal", (amf_recal_kernel<double>), dim3((unsigned)cdiv(n, 128)), dim3(128), 0, sat_pmid, sat_sw, nzs,
+                     (const double*)ctm_pmid, (const double*)ctm_partial, nzc, tropopause, vcd, amf, n, new_amf, vcd_out, ctm_vcd);
+    }
+    return OISAT_OK;
+}
+
+extern "C" int oisat_column_sum(oisat_ctx* h, int dtype, const void* ctm_pmid, const void* ctm_partial, int nzc,
+                                const double* tropopause, const double* vcd, int64_t n, void* ctm_vcd) {
+    ARG_CHECK(h && ctm_pmid && ctm_partial && vcd && ctm_vcd && n > 0 && nzc >= 1);
+    ARG_CHECK(dtype == OISAT_F32 || dtype == OISAT_F64);
+    if (dtype == OISAT_F32) {
+        OISAT_LAUNCH(h, "column_sum", (column_sum_kernel<float>), dim3(stream_grid(n, 256)), dim3(256), 0, (const float*)ctm_pmid,
+                     (const float*)ctm_partial, nzc, tropopause, vcd, n, (float*)ctm_vcd);
+    } else {
+        OISAT_LAUNCH(h, "column_sum", (column_sum_kernel<double>), dim3(stream_grid(n, 256)), dim3(256), 0, (const double*)ctm_pmid,
+                     (const double*)ctm_partial, nzc, tropopause, vcd, n, (double*)ctm_vcd);
+    }
+    return OISAT_OK;
+}

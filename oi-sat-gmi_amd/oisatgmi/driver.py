@@ -3,7 +3,7 @@
 Drop-in for the three methods of ``oisatgmi/driver.py`` that lie on the optimal-interpolation
 path: ``average`` (:53-63), ``bias_correct`` (:65-106) and ``oi`` (:108-114), with the same
 attribute names set on ``self``.  The I/O methods of the reference's class (``read_data``,
-``recal_amf``, ``cal_pwv``, ``conv_ak``, ``reporting``, ``savedaily``) are file
+``cal_pwv``, ``conv_ak``, ``reporting``, ``savedaily``) are file
 formats, plotting and sensor-specific operators outside this path; ``write_to_nc`` (the output stage,
 SURVEY.md section 8(f) row 4) is kept: same variables, with the scaling-factor rule evaluated on the device:
 they raise ``NotImplementedError`` here -- see INTEGRATION.md for binding the HIP path into the
@@ -145,8 +145,9 @@ class oisatgmi(object):
     def read_data(self, *a, **k):
         self._out_of_scope("read_data")
 
-    def recal_amf(self, *a, **k):
-        self._out_of_scope("recal_amf")
+    def recal_amf(self):
+        from .amf_recal import amf_recal
+        self.reader_obj.sat_data = amf_recal(self.reader_obj.ctm_data, self.reader_obj.sat_data)
 
     def cal_pwv(self, *a, **k):
         self._out_of_scope("cal_pwv")

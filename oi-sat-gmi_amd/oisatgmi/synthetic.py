@@ -233,3 +233,56 @@ def regional_ctm_grid(lat0: float, lat1: float, lon0: float, lon1: float, dlat: 
     lon = np.arange(lon0, lon1 + 1e-9, dlon)
     lon2, lat2 = np.meshgrid(lon, lat)
     return {"Latitude": lat2, "Longitude": lon2}
+
+
+def ctm_days(ny: int, nx: int, nz: int, ndays: int, seed: int, averaged: bool = False, dtype=np.float32,
+             lat0=-30.0, lat1=30.0, lon0=-40.0, lon1=40.0, year=2019, month=6):
+    """Model records as ``amf_recal`` consumes them (amf_recal.py:39-49,:124-131): one ``ctm_model`` per day
+    with 8 three-hourly slots (gas_profile, pressure_mid, delta_p of shape (8, nz, ny, nx)), or, with
+    ``averaged=True``, a single record holding the month's mean diurnal cycle."""
+    from .config import ctm_model
+    rng = np.random.default_rng(seed)
+    lat = np.linspace(lat0, lat1, ny)
+    lon = np.linspace(lon0, lon1, nx)
+    lon2, lat2 = np.meshgrid(lon, lat)
+    # pressure levels: surface (index 0) to top, hPa, with a little horizontal variation
+    edges = np.linspace(1000.0, 50.0, nz + 1)
+    pm = 0.5 * (edges[:-1] + edges[1:])
+    dp = (edges[:-1] - edges[1:])
+    out = []
+    for d in range(1 if averaged else ndays):
+        times = [_dt.datetime(year, month, 1 + d, 3 * h, 0) for h in range(8)]
+        wob = 1.0 + 0.01 * rng.normal(size=(8, 1, ny, nx))
+        pmid = (pm[None, :, None, None] * wob).astype(dtype)
+        delp = (dp[None, :, None, None] * wob).astype(dtype)
+        prof = (rng.lognormal(mean=-1.0, sigma=0.5, size=(8, nz, ny, nx)) * np.exp(-np.arange(nz) / 6.0)[None, :, None, None]).astype(dtype)
+        out.append(ctm_model(lat2, lon2, times, prof, pmid, np.zeros_like(pmid), delp, "GMI", averaged))
+    return out
+
+
+def amf_granules(ctm, nzs: int, k: int, seed: int, with_sw: bool = True, with_trop: bool = True):
+    """``k`` regridded granules on the model grid (``ctm_upscaled_needed=False``) carrying what the AMF
+    recalculation needs: scattering weights and their pressure grid (level-major), AMF, tropopause."""
+    from .config import satellite_amf
+    rng = np.random.default_rng(seed)
+    lat2, lon2 = ctm[0].latitude, ctm[0].longitude
+    ny, nx = lat2.shape
+    out = []
+    for g in range(k):
+        when = _dt.datetime(2019, 6, 1 + g % 2, 13, 20 + g)
+        vcd = rng.uniform(0.5, 8.0, size=(ny, nx))
+        vcd[rng.uniform(size=vcd.shape) < 0.2] = np.nan
+        amf = rng.uniform(0.6, 2.5, size=(ny, nx))
+        unc = rng.uniform(0.1, 1.0, size=(ny, nx))
+        if with_sw:
+            # satellite levels top-down or bottom-up, alternating: interp1d must sort them
+            p = np.linspace(1020.0, 20.0, nzs)[:, None, None] * (1 + 0.005 * rng.normal(size=(nzs, ny, nx)))
+            if g % 2:
+                p = p[::-1].copy()
+            sw = rng.uniform(0.2, 2.0, size=(nzs, ny, nx))
+        else:
+            p, sw = np.empty((1)), np.empty((1))
+        trop = rng.uniform(80.0, 300.0, size=(ny, nx)) if with_trop else np.empty((1))
+        out.append(satellite_amf(vcd, amf, when, trop, lat2, lon2, [], [], unc, [], p, sw, False, [], [], [], []))
+    out.insert(1, None)
+    return out

@@ -339,6 +339,97 @@ def interpolator(interpolator_type, grid_size, sat_data, ctm_models_coordinate, 
 
 
 # --------------------------------------------------------------------------------------------
+# amf_recal.py  (upstream of the averaging)
+# --------------------------------------------------------------------------------------------
+def partial_column(deltap, profile):
+    """amf_recal.py:51-56."""
+    return deltap * profile / 9.80665 / 28.97e-3 * 6.02214076e23 * 1e-4 * 1e-15 * 100.0 * 1e-9
+
+
+def _flat_time(t):
+    return t.year * 10000 + t.month * 100 + t.day + t.hour / 24.0 + t.minute / 60.0 / 24.0 + t.second / 3600.0 / 24.0
+
+
+def _hour_time(t):
+    return t.hour / 24.0 + t.minute / 60.0 / 24.0 + t.second / 3600.0 / 24.0
+
+
+def amf_pixel(sat_p, sat_sw, ctm_p, ctm_pc, trop):
+    """One pixel of _vertical_interp_and_amf (amf_recal.py:101-118): returns (new_amf, model_vcd)."""
+    f = _interp1d(np.log(sat_p), sat_sw, fill_value="extrapolate")
+    with np.errstate(all="ignore"):
+        sw = f(np.log(ctm_p))
+    sw[np.isinf(sw)] = 0.0
+    pc = np.array(ctm_pc, copy=True)                # keeps the model's dtype: np.nansum(float32) accumulates in float32
+    if trop is not None:
+        m = ctm_p < trop
+        sw[m] = np.nan
+        pc[m] = np.nan
+    scd = np.nansum(sw * pc)
+    vcd = np.nansum(pc)
+    return (scd / vcd if vcd != 0 else np.nan), vcd
+
+
+def amf_recal(ctm_data, sat_data):
+    """Restatement of ``amf_recal`` (amf_recal.py:121-185) for granules already on the model grid or
+    needing the model upscaled (:154-158).  Mutates and returns ``sat_data`` like the reference."""
+    tc, th = [], []
+    for rec in ctm_data:
+        tc += [_flat_time(t) for t in rec.time]
+        th += [_hour_time(t) for t in rec.time]
+    tc, th = np.array(tc), np.array(th)
+    for L2 in sat_data:
+        if L2 is None:
+            continue
+        if not ctm_data[0].averaged:
+            ci = int(np.argmin(np.abs(_flat_time(L2.time) - tc)))
+            day, hour = int(np.floor(ci / 8.0)), int(ci % 8)
+        else:
+            ci = int(np.argmin(np.abs(_hour_time(L2.time) - th)))
+            day, hour = 0, ci
+        pmid = ctm_data[day].pressure_mid[hour].squeeze()
+        prof = ctm_data[day].gas_profile[hour].squeeze()
+        delp = ctm_data[day].delta_p[hour].squeeze()
+        pc = partial_column(delp, prof)
+        if L2.ctm_upscaled_needed:
+            coord = {"Longitude": L2.longitude_center, "Latitude": L2.latitude_center}
+            thr = np.sqrt(np.abs(coord["Longitude"][0, 0] - coord["Longitude"][0, 1]) ** 2 +
+                          np.abs(coord["Latitude"][0, 0] - coord["Latitude"][1, 0]) ** 2)
+            clon, clat = ctm_data[0].longitude, ctm_data[0].latitude
+            gs = np.sqrt(np.abs(clon[0, 0] - clon[0, 1]) ** 2 + np.abs(clat[0, 0] - clat[1, 0]) ** 2)
+            pmid = np.stack([upscaler(clon, clat, pmid[z], coord, gs, thr)[2] for z in range(pmid.shape[0])])
+            pc = np.stack([upscaler(clon, clat, pc[z], coord, gs, thr)[2] for z in range(pc.shape[0])])
+        has_trop = np.size(L2.tropopause) != 1
+        if np.size(L2.scattering_weights) == 1:
+            pc = np.array(pc, copy=True)
+            if has_trop:
+                for z in range(pc.shape[0]):
+                    pc[z][pmid[z] < L2.tropopause] = np.nan
+            mv = np.nansum(pc, axis=0)
+            mv[np.isnan(L2.vcd)] = np.nan
+            L2.ctm_vcd, L2.ctm_time_at_sat = mv, tc[ci]
+            L2.old_amf, L2.new_amf = np.empty((1)), np.empty((1))
+            continue
+        new_amf = np.full_like(L2.vcd, np.nan)
+        mv = np.full_like(L2.vcd, np.nan)
+        for i in range(L2.vcd.shape[0]):
+            for j in range(L2.vcd.shape[1]):
+                if np.isnan(L2.vcd[i, j]):
+                    continue
+                new_amf[i, j], mv[i, j] = amf_pixel(L2.pressure_mid[:, i, j], L2.scattering_weights[:, i, j], pmid[:, i, j],
+                                                    pc[:, i, j], L2.tropopause[i, j] if has_trop else None)
+        L2.old_amf = L2.amf
+        new_amf[np.isnan(L2.vcd)] = np.nan
+        L2.new_amf = new_amf
+        with np.errstate(all="ignore"):
+            L2.vcd = (L2.amf * L2.vcd) / new_amf
+        mv[np.isnan(L2.vcd)] = np.nan
+        mv[np.isinf(L2.vcd)] = np.nan
+        L2.ctm_vcd, L2.ctm_time_at_sat = mv, tc[ci]
+    return sat_data
+
+
+# --------------------------------------------------------------------------------------------
 # Dense Gaussian-B OI (north-star extension; NO reference counterpart -> parity unpinned)
 # --------------------------------------------------------------------------------------------
 def unit_vectors(lat_deg, lon_deg):

@@ -5,7 +5,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG_PARENT = os.path.join(ROOT, "oi-sat-gmi_amd")
-for p in (ROOT, PKG_PARENT):
+for p in (ROOT, PKG_PARENT, os.path.join(ROOT, 'tests')):
     if p not in sys.path:
         sys.path.insert(0, p)
 

@@ -65,6 +65,7 @@ from oisatgmi.optimal_interpolation import OI as REF_OI                 # noqa: 
 from oisatgmi.averaging import averaging as REF_averaging, error_averager as REF_error_averager  # noqa: E402
 from oisatgmi import interpolator as REF_interp                         # noqa: E402
 from oisatgmi import config as REF_cfg                                  # noqa: E402
+from oisatgmi.amf_recal import amf_recal as REF_amf_recal               # noqa: E402
 
 
 def quiet(fn, *a, **k):
@@ -214,6 +215,50 @@ def gen_interpolator():
     save("interpolator.npz", **out)
 
 
+def amf_cases():
+    """name -> (ctm_data, sat_data) builders shared with the tests (seeded)"""
+    def case_a():
+        ctm = syn.ctm_days(10, 14, 12, 2, 9101, averaged=False)
+        return ctm, syn.amf_granules(ctm, 9, 3, 9102, with_sw=True, with_trop=True)
+
+    def case_b():
+        ctm = syn.ctm_days(8, 9, 20, 1, 9201, averaged=True, dtype=np.float64)
+        return ctm, syn.amf_granules(ctm, 35, 2, 9202, with_sw=True, with_trop=False)
+
+    def case_c():
+        ctm = syn.ctm_days(10, 14, 12, 2, 9301, averaged=False)
+        return ctm, syn.amf_granules(ctm, 9, 2, 9302, with_sw=False, with_trop=True)
+
+    def case_d():                           # model finer than the satellite grid: upscaling needed
+        ctm = syn.ctm_days(49, 65, 6, 1, 9401, averaged=True, lat0=-12.0, lat1=12.0, lon0=-16.0, lon1=16.0)
+        coarse = syn.ctm_days(9, 11, 6, 1, 9402, averaged=True, lat0=-10.0, lat1=10.0, lon0=-12.5, lon1=12.5)
+        sat = syn.amf_granules(coarse, 7, 2, 9403, with_sw=True, with_trop=True)
+        for s in sat:
+            if s is not None:
+                s.ctm_upscaled_needed = True
+        return ctm, sat
+    return {"a": case_a, "b": case_b, "c": case_c, "d": case_d}
+
+
+def gen_amf_recal():
+    out = {}
+    for tag, build in amf_cases().items():
+        ctm, sat = build()
+        ref_ctm = [to_ref(c) for c in ctm]
+        ref_sat = [to_ref(s) for s in sat]
+        res = quiet(REF_amf_recal, ref_ctm, ref_sat)
+        k = 0
+        for r in res:
+            if r is None:
+                continue
+            for f in ("vcd", "ctm_vcd", "new_amf", "old_amf"):
+                out[f"{tag}_{k}_{f}"] = np.asarray(getattr(r, f), dtype=np.float64)
+            out[f"{tag}_{k}_time"] = np.float64(r.ctm_time_at_sat)
+            k += 1
+        out[f"{tag}_n"] = k
+    save("amf_recal.npz", **out)
+
+
 def gen_records():
     out = {}
     for nm in ("satellite_amf", "satellite_opt", "satellite_ssmis", "ctm_model"):
@@ -232,4 +277,5 @@ if __name__ == "__main__":
     gen_averaging()
     gen_upscaler()
     gen_interpolator()
+    gen_amf_recal()
     print("done")

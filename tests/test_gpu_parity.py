@@ -359,6 +359,40 @@ def test_driver_methods(ctx, golden):
 
 
 # ------------------------------------------------------------------------------------------------
+# amf_recal.py
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_amf_recal_matches_reference(ctx, golden, tag):
+    from amf_cases import amf_cases, check_against_golden
+    from oisatgmi.amf_recal import amf_recal
+    ctm, sat = amf_cases()[tag]()
+    # float64 model cubes: the reference's operation order, only log() may differ by an ulp -> 1e-11.
+    # float32 model cubes (cases a, c): NumPy evaluates np.log(ctm_p) in float32 with a few-ulp SIMD
+    # routine; the device uses the correctly rounded float32 log, and an ulp of log p (4e-7) times the
+    # slope of the scattering-weight profile is what is left: 1e-5.
+    rtol = 1e-11 if tag in ("b", "d") else 1e-5
+    check_against_golden(golden("amf_recal.npz"), tag, amf_recal(ctm, sat), rtol=rtol)
+
+
+def test_amf_recal_larger_against_oracle(ctx):
+    from oisatgmi.amf_recal import amf_recal
+    import copy
+    ctm = syn.ctm_days(40, 60, 72, 2, 777, averaged=False, dtype=np.float64)
+    sat = syn.amf_granules(ctm, 35, 3, 778, with_sw=True, with_trop=True)
+    sat[0].pressure_mid[3, 5, 7] = np.nan                       # a broken satellite level
+    sat[0].scattering_weights[:, 2, 2] = 0.0
+    ref = orc.amf_recal(ctm, copy.deepcopy(sat))
+    got = amf_recal(ctm, sat)
+    o = oisatgmi()
+    for a, b in zip(got, ref):
+        if a is None:
+            assert b is None
+            continue
+        for f in ("vcd", "ctm_vcd", "new_amf"):
+            np.testing.assert_allclose(getattr(a, f), getattr(b, f), rtol=1e-10, equal_nan=True, err_msg=f)
+
+
+# ------------------------------------------------------------------------------------------------
 # interpolator.py
 # ------------------------------------------------------------------------------------------------
 def test_upscaler_matches_reference(ctx, golden):

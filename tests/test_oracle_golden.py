@@ -151,3 +151,10 @@ def test_dense_limit_reduces_to_diag():
     np.testing.assert_array_equal(r["xa"][un], c.Xa.ravel()[un])
     np.testing.assert_allclose(r["ak_obs"], ak.ravel()[cells], rtol=1e-10)
     np.testing.assert_allclose(r["err"][cells], err.ravel()[cells], rtol=1e-10)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_amf_recal(golden, tag):
+    from amf_cases import amf_cases, check_against_golden
+    ctm, sat = amf_cases()[tag]()
+    check_against_golden(golden("amf_recal.npz"), tag, orc.amf_recal(ctm, sat), rtol=1e-12)
