@@ -333,7 +333,15 @@ def interpolator(interpolator_type, grid_size, sat_data, ctm_models_coordinate, 
             trop = np.empty((1))
         _, _, unc, _ = regrid(sat_data.uncertainty ** 2 * mask, error=True)
         unc = np.sqrt(unc)
-    fields = (vcd, amf, sat_data.time, trop, uy, ux, [], [], unc, [], np.empty((1)), np.empty((1)),
+        # per-level cubes of the two-step retrievals, interpolator.py:191-213
+        if np.size(sat_data.scattering_weights) != 1:
+            nz = np.shape(sat_data.pressure_mid)[0]
+            sw = np.stack([regrid(np.squeeze(sat_data.scattering_weights[z]) * mask)[2] for z in range(nz)])
+            pm = np.stack([regrid(np.squeeze(sat_data.pressure_mid[z]) * mask)[2] for z in range(nz)])
+        else:
+            sw = np.empty((1))
+            pm = np.zeros((np.shape(sat_data.pressure_mid)[0], np.shape(ux)[0], np.shape(ux)[1]))
+    fields = (vcd, amf, sat_data.time, trop, uy, ux, [], [], unc, [], pm, sw,
               need, [], [], [], [])
     return record_type(*fields) if record_type is not None else fields
 

@@ -732,3 +732,57 @@ def test_rccl_plumbing_world_size_one(ctx):
     finally:
         ctx.set_stream(None)
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------
+# the whole month, in the order run/job.py calls it (job.py:61-86): regrid every granule, recalculate the
+# AMFs, average, bias-correct, analyse, write -- product against the oracle chained the same way
+# ------------------------------------------------------------------------------------------------
+def test_month_pipeline_end_to_end(ctx, tmp_path):
+    import copy
+    from oisatgmi.amf_recal import amf_recal
+    nz_c, nz_s, ngran = 10, 8, 6
+    ctm = syn.ctm_days(41, 57, nz_c, 2, 6100, averaged=False, dtype=np.float64, lat0=-20.0, lat1=20.0, lon0=-28.0, lon1=28.0)
+    coord = {"Latitude": ctm[0].latitude, "Longitude": ctm[0].longitude}            # 1 deg model grid
+    rng = np.random.default_rng(6101)
+    swaths = []
+    for g in range(ngran):
+        s = syn.swath_granule(6200 + g, nscan=200, npix=50, lat0=-24.0 + g, lat1=24.0, lon_c=-12.0 + 5.0 * g, width_deg=30.0)
+        s.time = s.time.replace(day=1 + g % 2, minute=10 + g)
+        s.scattering_weights = rng.uniform(0.3, 2.0, size=(nz_s,) + s.vcd.shape)
+        s.pressure_mid = np.linspace(1010.0, 60.0, nz_s)[:, None, None] * (1 + 0.004 * rng.normal(size=(nz_s,) + s.vcd.shape))
+        s.tropopause = rng.uniform(90.0, 250.0, size=s.vcd.shape)
+        swaths.append(s)
+
+    def run(regrid, recal, avg, oi_fn, tag):
+        sat = [regrid(4, 0.25, copy.deepcopy(s), coord, 0.75) for s in swaths] + [None]
+        sat = recal(ctm, sat)
+        r = _Reader()
+        r.sat_data = sat
+        return sat, avg("2019-06-01", "2019-07-01", r)
+
+    sat_o, av_o = run(lambda *a: orc.interpolator(*a, record_type=cfg.satellite_amf), orc.amf_recal,
+                      lambda a, b, r: orc.averaging(a, b, r, amf_type=cfg.satellite_amf, opt_type=cfg.satellite_opt), None, "oracle")
+    sat_p, av_p = run(interpolator, amf_recal, averaging, None, "product")
+    for a, b in zip(sat_p, sat_o):
+        assert (a is None) == (b is None)
+        if a is not None:
+            for f in ("vcd", "ctm_vcd", "new_amf", "uncertainty"):
+                np.testing.assert_allclose(getattr(a, f), getattr(b, f), rtol=1e-10, equal_nan=True, err_msg=f)
+    for a, b in zip(av_p[:5], av_o[:5]):
+        np.testing.assert_allclose(a, b, rtol=1e-10, equal_nan=True)
+    assert np.isfinite(av_p[0]).sum() > 200
+    o = oisatgmi()
+    o.reader_obj = _Reader()
+    o.reader_obj.sat_data = sat_p
+    o.reader_obj.ctm_data = ctm
+    o.average("2019-06-01", "2019-07-01", gasname="NO2")
+    o.bias_correct("OMI", "NO2")
+    y_before = o.sat_averaged_vcd.copy()
+    o.oi("OMI", error_ctm=50.0)
+    Xa, Y, Sa, So = orc.driver_oi_inputs(av_o[2], orc.bias_correct(av_o[0], "OMI", "NO2"), av_o[1], av_o[3], av_o[4], "OMI", 50.0)
+    ref = orc.OI(Xa.copy(), Y.copy(), Sa, So, regularization_on=True)
+    for a, b in zip((o.ctm_averaged_vcd_corrected, o.ak_OI, o.increment_OI, o.error_OI), ref[:4]):
+        np.testing.assert_allclose(a, b, rtol=1e-9, equal_nan=True)
+    path = o.write_to_nc("NO2_201906", str(tmp_path))
+    assert os.path.getsize(path) > 11 * 4 * Xa.size
