@@ -36,13 +36,6 @@ constexpr int NB = 128;          // diagonal block / tile edge
 constexpr int BK = 32;           // K step
 constexpr int LDSW = 36;         // padded LDS row stride in floats (144 B, 16-B aligned)
 
-struct ChFactor {                // what potrs needs besides L: the inverted diagonal blocks
-    const float* S = nullptr;
-    int64_t m = 0, mp = 0, ld = 0;
-    float* tinv = nullptr;       // [mp/NB][NB][NB]: inverted diagonal blocks, row-major
-};
-static thread_local ChFactor g_factor;   // one factor per host thread (one handle per thread/GPU)
-
 // ---- gemm_nt ---------------------------------------------------------------------------------
 // mode 0: C -= A*B^T      mode 1: C = A*B^T (C may alias A when N == K == 128: TRSM-as-GEMM)
 // lower != 0: the C region is anchored on the diagonal; tiles strictly above it are skipped.
@@ -687,11 +680,11 @@ extern "C" int oisat_potrf(oisat_ctx* h, float* S, int64_t m, int64_t ld, int* i
     }
     const int rc = potrf_rec(h, S, ld, mpb, 0, mpb, tinv, info_dev);
     if (rc) return rc;
-    g_factor.S = S;
-    g_factor.m = m;
-    g_factor.mp = mp;
-    g_factor.ld = ld;
-    g_factor.tinv = tinv;
+    h->factor.S = S;
+    h->factor.m = m;
+    h->factor.mp = mp;
+    h->factor.ld = ld;
+    h->factor.tinv = tinv;
     if (info_host) {
         int* pin = (int*)oisat_pinned(h, 64);
         if (!pin) return OISAT_ENOMEM;
@@ -708,14 +701,14 @@ extern "C" int oisat_potrf(oisat_ctx* h, float* S, int64_t m, int64_t ld, int* i
 
 extern "C" int oisat_potrs(oisat_ctx* h, const float* L, int64_t m, int64_t ld, double* z_inout) {
     ARG_CHECK(h && L && z_inout && m > 0);
-    ARG_CHECK(g_factor.S == L && g_factor.m == m && g_factor.ld == ld);     // must follow oisat_potrf of this matrix
-    double* w = (double*)oisat_ws(h, 5, sizeof(double) * 2 * g_factor.mp);
+    ARG_CHECK(h->factor.S == L && h->factor.m == m && h->factor.ld == ld);     // must follow oisat_potrf of this matrix
+    double* w = (double*)oisat_ws(h, 5, sizeof(double) * 2 * h->factor.mp);
     if (!w) return OISAT_ENOMEM;
     double* rhs = w;
-    double* tmp = w + g_factor.mp;
-    OISAT_LAUNCH(h, "copy_pad", copy_pad_kernel, dim3(stream_grid(g_factor.mp, 256)), dim3(256), 0, (const double*)z_inout, m,
-                 g_factor.mp, rhs);
-    const int rc = trsv_solve(h, g_factor, rhs, tmp);
+    double* tmp = w + h->factor.mp;
+    OISAT_LAUNCH(h, "copy_pad", copy_pad_kernel, dim3(stream_grid(h->factor.mp, 256)), dim3(256), 0, (const double*)z_inout, m,
+                 h->factor.mp, rhs);
+    const int rc = trsv_solve(h, h->factor, rhs, tmp);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(z_inout, rhs, sizeof(double) * m, hipMemcpyDeviceToDevice, h->stream));
     return OISAT_OK;
@@ -727,7 +720,7 @@ extern "C" int oisat_cov_residual(oisat_ctx* h, const double* oxyz, const double
 extern "C" int oisat_gain_solve(oisat_ctx* h, const float* L, const double* oxyz, const double* osig, const double* ovar, int64_t m,
                                 int64_t ld, double g, const double* d, int refine, double* z_out, double* resid_host) {
     ARG_CHECK(h && L && oxyz && osig && ovar && d && z_out && m > 0 && refine >= 0 && refine <= 8);
-    ARG_CHECK(g_factor.S == L && g_factor.m == m && g_factor.ld == ld);
+    ARG_CHECK(h->factor.S == L && h->factor.m == m && h->factor.ld == ld);
     double* r = (double*)oisat_ws(h, 6, sizeof(double) * (m + 16));
     if (!r) return OISAT_ENOMEM;
     double* nrm_dev = r + m;
@@ -764,17 +757,17 @@ extern "C" int oisat_gain_solve(oisat_ctx* h, const float* L, const double* oxyz
 
 extern "C" int oisat_trsm_rows(oisat_ctx* h, const float* L, int64_t m, int64_t ld, float* X, int64_t nrows, int64_t ldx) {
     ARG_CHECK(h && L && X && m > 0 && nrows > 0);
-    ARG_CHECK(g_factor.S == L && g_factor.m == m && g_factor.ld == ld);     // must follow oisat_potrf of this matrix
-    ARG_CHECK(nrows % NB == 0 && ldx >= g_factor.mp && ldx % 4 == 0 && ((uintptr_t)X % 16) == 0);
-    return trsm_rows_rec(h, g_factor, X, nrows, ldx, 0, g_factor.mp / NB);
+    ARG_CHECK(h->factor.S == L && h->factor.m == m && h->factor.ld == ld);     // must follow oisat_potrf of this matrix
+    ARG_CHECK(nrows % NB == 0 && ldx >= h->factor.mp && ldx % 4 == 0 && ((uintptr_t)X % 16) == 0);
+    return trsm_rows_rec(h, h->factor, X, nrows, ldx, 0, h->factor.mp / NB);
 }
 
 extern "C" int oisat_posterior_error(oisat_ctx* h, const float* L, int64_t m, int64_t ld, const double* gxyz, const double* gsig,
                                      int64_t n, int64_t i0, int64_t i1, const double* oxyz, const double* osig, double g,
                                      int64_t chunk_rows, float* err) {
     ARG_CHECK(h && L && gxyz && gsig && oxyz && osig && err && m > 0 && n > 0 && 0 <= i0 && i0 < i1 && i1 <= n);
-    ARG_CHECK(g_factor.S == L && g_factor.m == m && g_factor.ld == ld);
-    const int64_t mp = g_factor.mp;
+    ARG_CHECK(h->factor.S == L && h->factor.m == m && h->factor.ld == ld);
+    const int64_t mp = h->factor.mp;
     if (chunk_rows <= 0) chunk_rows = 4096;
     chunk_rows = cdiv(chunk_rows, NB) * NB;
     float* X = (float*)oisat_ws(h, 6, sizeof(float) * chunk_rows * mp + sizeof(double) * chunk_rows);
@@ -787,7 +780,7 @@ extern "C" int oisat_posterior_error(oisat_ctx* h, const float* L, int64_t m, in
         OISAT_LAUNCH(h, "cross_cov_rows", cross_cov_rows_kernel, dim3((unsigned)(mp / 64), (unsigned)(nrows / 64)), dim3(256), 0,
                      gxyz, gsig, n, c0, live, oxyz, osig, m, mp, g2, X, mp);
         if (nrows > live) HIP_TRY(hipMemsetAsync(X + live * mp, 0, sizeof(float) * (nrows - live) * mp, h->stream));
-        const int rc = trsm_rows_rec(h, g_factor, X, nrows, mp, 0, mp / NB);
+        const int rc = trsm_rows_rec(h, h->factor, X, nrows, mp, 0, mp / NB);
         if (rc) return rc;
         OISAT_LAUNCH(h, "row_sumsq", row_sumsq_kernel, dim3((unsigned)cdiv(nrows * 64, 256)), dim3(256), 0, (const float*)X, nrows, mp,
                      mp, ss);
@@ -800,8 +793,8 @@ extern "C" int oisat_posterior_error(oisat_ctx* h, const float* L, int64_t m, in
 extern "C" int oisat_gain_diag(oisat_ctx* h, const float* L, int64_t m, int64_t ld, const double* ovar, int64_t chunk_rows,
                                double* ak_out) {
     ARG_CHECK(h && L && ovar && ak_out && m > 0);
-    ARG_CHECK(g_factor.S == L && g_factor.m == m && g_factor.ld == ld);
-    const int64_t mp = g_factor.mp;
+    ARG_CHECK(h->factor.S == L && h->factor.m == m && h->factor.ld == ld);
+    const int64_t mp = h->factor.mp;
     if (chunk_rows <= 0) chunk_rows = 4096;
     chunk_rows = cdiv(chunk_rows, NB) * NB;
     float* X = (float*)oisat_ws(h, 6, sizeof(float) * chunk_rows * mp + sizeof(double) * chunk_rows);
@@ -811,7 +804,7 @@ extern "C" int oisat_gain_diag(oisat_ctx* h, const float* L, int64_t m, int64_t 
         const int64_t live = (m - a0 < chunk_rows) ? m - a0 : chunk_rows;
         const int64_t nrows = cdiv(live, NB) * NB;
         OISAT_LAUNCH(h, "identity_rows", identity_rows_kernel, dim3(stream_grid(nrows * mp, 256)), dim3(256), 0, X, mp, a0, nrows, mp);
-        const int rc = trsm_rows_rec(h, g_factor, X, nrows, mp, 0, mp / NB);
+        const int rc = trsm_rows_rec(h, h->factor, X, nrows, mp, 0, mp / NB);
         if (rc) return rc;
         OISAT_LAUNCH(h, "row_sumsq", row_sumsq_kernel, dim3((unsigned)cdiv(nrows * 64, 256)), dim3(256), 0, (const float*)X, nrows, mp,
                      mp, ss);

@@ -28,6 +28,12 @@ struct ProfPending {
     hipEvent_t a, b;
 };
 
+struct ChFactor {                // what the triangular solves need besides L: the inverted diagonal blocks
+    const float* S = nullptr;
+    int64_t m = 0, mp = 0, ld = 0;
+    float* tinv = nullptr;       // [mp/128][128][128]: inverted diagonal blocks, row-major
+};
+
 struct oisat_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -46,6 +52,9 @@ struct oisat_ctx {
     double scales_host[OISAT_MAX_SCALES] = {0};
     int scales_n = 0;
     const void* scales_dev = nullptr;
+    // the factor left by the last oisat_potrf on this handle (dense_chol.hip)
+    ChFactor factor;
+    hipStream_t own_stream = nullptr;   // created by oisat_stream_create, destroyed at shutdown
     // pinned host scratch for small synchronous read-backs
     void* pinned = nullptr;
     size_t pinned_bytes = 0;

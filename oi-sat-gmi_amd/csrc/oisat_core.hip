@@ -51,6 +51,7 @@ extern "C" void oisat_shutdown(oisat_ctx* h) {
     for (int i = 0; i < 8; ++i)
         if (h->ws[i]) (void)hipFree(h->ws[i]);
     if (h->pinned) (void)hipHostFree(h->pinned);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
 
@@ -65,6 +66,13 @@ extern "C" int oisat_device_info(oisat_ctx* h, char* name_out, int name_cap, int
 extern "C" int oisat_set_stream(oisat_ctx* h, void* hip_stream) {
     ARG_CHECK(h != nullptr);
     h->stream = (hipStream_t)hip_stream;
+    return OISAT_OK;
+}
+
+extern "C" int oisat_stream_create(oisat_ctx* h) {
+    ARG_CHECK(h != nullptr);
+    if (!h->own_stream) HIP_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    h->stream = h->own_stream;
     return OISAT_OK;
 }
 

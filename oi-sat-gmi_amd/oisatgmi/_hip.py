@@ -29,6 +29,7 @@ SIGNATURES = {
     "oisat_version": (C.c_char_p, []),
     "oisat_device_info": (C.c_int, [_c_ctx, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(_i64)]),
     "oisat_set_stream": (C.c_int, [_c_ctx, _ptr]),
+    "oisat_stream_create": (C.c_int, [_c_ctx]),
     "oisat_sync": (C.c_int, [_c_ctx]),
     "oisat_dmalloc": (C.c_int, [_c_ctx, C.c_size_t, C.POINTER(_ptr)]),
     "oisat_dfree": (C.c_int, [_c_ctx, _ptr]),
@@ -203,6 +204,11 @@ class Context:
 
     def set_stream(self, stream_handle: int | None):
         self.check(self.lib.oisat_set_stream(self.h, stream_handle or None))
+
+    def own_stream(self):
+        """Give this handle a stream of its own (used for concurrent tiles)."""
+        self.check(self.lib.oisat_stream_create(self.h))
+        return self
 
     def sync(self):
         self.check(self.lib.oisat_sync(self.h))

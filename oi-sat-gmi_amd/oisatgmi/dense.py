@@ -211,8 +211,11 @@ class TiledAnalysis:
     tile's observations + halo), run back to back on the stream with ONE shared factor workspace.
     Tiles are independent work units -- ``parallel.shard_units`` spreads (month x tile) over GPUs."""
 
-    def __init__(self, grid_lat, grid_lon, tile_deg=30.0, halo_km=900.0, dtype=np.float32, ctx=None):
+    def __init__(self, grid_lat, grid_lon, tile_deg=30.0, halo_km=900.0, dtype=np.float32, ctx=None, streams=6):
         self.ctx = ctx or _hip.context()
+        # extra handles on the same device, each with its own stream, workspaces and factor: tiles are
+        # independent, and a 4,000-8,000-observation solve leaves most of the 256 CUs idle on its own
+        self.lanes = [self.ctx] + [_hip.Context(self.ctx.device).own_stream() for _ in range(max(0, int(streams) - 1))]
         self.lat2, self.lon2 = np.asarray(grid_lat), np.asarray(grid_lon)
         self.tile_deg, self.halo_km = float(tile_deg), float(halo_km)
         self.dt = np.dtype(dtype)
@@ -228,17 +231,23 @@ class TiledAnalysis:
         s_all = sig.ravel()[cell]
         ovar = np.ravel(obs_var)
         self.tiles = [t for t in tile_partition(self.lat2, self.lon2, olat, olon, self.tile_deg, self.halo_km)]
-        mmax = max((t["obs"].size for t in self.tiles), default=0)
-        mp = -(-max(mmax, 1) // NB) * NB
-        self.S = self.ctx.alloc(mp * mp * 4)
+        # largest tiles first, dealt round-robin to the lanes (each lane: one stream, one shared factor workspace)
+        order = sorted(range(len(self.tiles)), key=lambda i: -self.tiles[i]["obs"].size)
+        lane_of = {ti: k % len(self.lanes) for k, ti in enumerate(order)}
+        self.S = []
+        for li, lane in enumerate(self.lanes):
+            mmax = max((self.tiles[ti]["obs"].size for ti in order if lane_of[ti] == li), default=0)
+            mp = -(-max(int(mmax), 1) // NB) * NB
+            self.S.append(lane.alloc(mp * mp * 4))
         self.plans = []
-        for t in self.tiles:
+        for ti, t in enumerate(self.tiles):
             (y0, y1), (x0, x1) = t["rows"], t["cols"]
             if t["obs"].size == 0:
                 self.plans.append(None)
                 continue
+            li = lane_of[ti]
             p = DenseAnalysis(self.lat2[y0:y1, x0:x1], self.lon2[y0:y1, x0:x1], max_obs=int(t["obs"].size), dtype=self.dt,
-                              ctx=self.ctx, shared_S=self.S)
+                              ctx=self.lanes[li], shared_S=self.S[li])
             p.load_background(Xa[y0:y1, x0:x1], np.asarray(Sa)[y0:y1, x0:x1], scale=scale)
             o = t["obs"]
             p.load_obs_direct(olat[o], olon[o], s_all[o], ovar[o], d_all[o])
@@ -247,10 +256,16 @@ class TiledAnalysis:
         self.n = int(Xa.size)
         self.flops = sum(DenseAnalysis.flops(int(t["obs"].size)) for t in self.tiles if t["obs"].size)
 
+        self._order = [ti for ti in order if self.plans[ti] is not None]
+
     def run(self, L_km, refine=1, check_pd=False):
-        for p in self.plans:
-            if p is not None:
-                p.run(L_km, refine=refine, check_pd=check_pd)
+        """Enqueue every tile on its lane's stream (largest first) and wait for all lanes."""
+        main_stream_work = self.ctx
+        main_stream_work.sync()                         # inputs uploaded on the default stream are complete
+        for ti in self._order:
+            self.plans[ti].run(L_km, refine=refine, check_pd=check_pd)
+        for lane in self.lanes:
+            lane.sync()
 
     def download(self):
         xa = self._Xa.astype(self.dt).copy()

@@ -786,3 +786,29 @@ def test_month_pipeline_end_to_end(ctx, tmp_path):
         np.testing.assert_allclose(a, b, rtol=1e-9, equal_nan=True)
     path = o.write_to_nc("NO2_201906", str(tmp_path))
     assert os.path.getsize(path) > 11 * 4 * Xa.size
+
+
+def test_c_abi_rejects_bad_arguments(ctx):
+    """Error behaviour of the boundary: negative status + message, never a crash or a silent no-op."""
+    lib = ctx.lib
+    buf = ctx.alloc(1024)
+    rc = lib.oisat_oi_apply(ctx.h, 7, buf.ptr, buf.ptr, buf.ptr, buf.ptr, 16, 1.0, buf.ptr, None, None, None)     # bad dtype
+    assert rc == -1 and b"dtype" in lib.oisat_last_error()
+    rc = lib.oisat_oi_apply(ctx.h, _hip.F32, None, buf.ptr, buf.ptr, buf.ptr, 16, 1.0, buf.ptr, None, None, None)  # NULL input
+    assert rc == -1
+    rc = lib.oisat_nanmean_stack(ctx.h, _hip.F32, buf.ptr, 0, 16, 0, buf.ptr)                                      # k = 0
+    assert rc == -1
+    rc = lib.oisat_gemm_nt(ctx.h, buf.ptr, 128, buf.ptr, 128, buf.ptr, 128, 100, 128, 128, 0, 0)                   # M not a multiple of 128
+    assert rc == -1
+    z = ctx.alloc(8 * 128)
+    rc = lib.oisat_potrs(ctx.h, buf.ptr, 128, 128, z.ptr)                                                          # no factorization of this matrix
+    assert rc == -1
+    with pytest.raises(_hip.OisatError):
+        ctx.check(rc)
+    with pytest.raises(TypeError):
+        _hip.dtype_code(np.int32)
+    # a second handle on the same device is independent (own workspaces, own factor)
+    other = _hip.Context(ctx.device).own_stream()
+    d = other.upload(np.arange(8.0))
+    np.testing.assert_array_equal(other.download(d.ptr, (8,), np.float64), np.arange(8.0))
+    other.close()
