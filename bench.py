@@ -323,7 +323,26 @@ def main():
             plan2.run(L2, refine=r2, check_pd=True)
             el2 = time_steps(lambda: plan2.run(L2, refine=r2), 20, 3, sync)
             roof2, per2 = roofline_leg(ctx, plan2, L2, r2, 5)
+            # several independent months in flight on one GPU (one handle + stream each): a 10^4-observation
+            # solve is a chain of small launches that leaves most CUs idle, months are independent work units
+            lanes = [_hip.Context(ctx.device).own_stream() for _ in range(3)]
+            plans = [plan2] + [make_plan(l, SECONDARY, 4001 + i) for i, l in enumerate(lanes)]
+            for pl in plans:
+                pl.run(L2, refine=r2)
+
+            def four_months():
+                for pl in plans:
+                    pl.run(L2, refine=r2)
+                for l in lanes:
+                    l.sync()
+            el4 = time_steps(four_months, 10, 2, sync)
+            conc = {"months_in_flight": 4, "value": 4 * ny2 * nx2 * 10 / el4, "unit": "grid-cells/s",
+                    "ms_per_month": 1e3 * el4 / 40}
+            del plans
+            for l in lanes:
+                l.close()
             out["secondary"] = {"workload": SECONDARY, "value": ny2 * nx2 * 20 / el2, "unit": "grid-cells/s",
+                                "concurrent": conc,
                                 "ms_per_step": 1e3 * el2 / 20, "obs_per_month": plan2.m,
                                 "solve_tflops_end_to_end": dense.DenseAnalysis.flops(plan2.m) / (el2 / 20) / 1e12,
                                 "roofline": roof2, "kernel_ms_per_step": per2}
