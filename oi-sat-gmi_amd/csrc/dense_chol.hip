@@ -389,13 +389,14 @@ struct TrsvCtl {                         // zeroed by hipMemsetAsync before ever
         q[0] = reg[p].x; q[1] = reg[p].y; q[2] = reg[p].z; q[3] = reg[p].w;                                    \
     }
 
-__device__ __forceinline__ bool wait_flag(unsigned* flag, TrsvCtl* ctl, int tid, unsigned* lds_ok) {
+__device__ __forceinline__ bool wait_flag(unsigned* flag, TrsvCtl* ctl, unsigned* err_total, int tid, unsigned* lds_ok) {
     if (tid == 0) {
         unsigned ok = 1, spins = 0;
         while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
             __builtin_amdgcn_s_sleep(1);
             if (++spins > (1u << 24) || __hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
                 __hip_atomic_store(&ctl->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                atomicAdd(err_total, 1u);                 // survives the per-sweep memset: read by checked solves
                 ok = 0;
                 break;
             }
@@ -410,7 +411,8 @@ __device__ __forceinline__ bool wait_flag(unsigned* flag, TrsvCtl* ctl, int tid,
 template <int TRANSPOSE>
 __global__ __launch_bounds__(256) void trsv_pipe_kernel(const float* __restrict__ L, int64_t ld, const float* __restrict__ tinv, int nb,
                                                          const double* __restrict__ rhs, double* __restrict__ sol,
-                                                         unsigned* __restrict__ flags, TrsvCtl* __restrict__ ctl) {
+                                                         unsigned* __restrict__ flags, TrsvCtl* __restrict__ ctl,
+                                                         unsigned* __restrict__ err_total) {
     extern __shared__ __attribute__((aligned(16))) float tile[];        // [128][TLD]
     __shared__ double vec[NB], part[NB];
     __shared__ unsigned s_ticket, s_ok;
@@ -432,7 +434,7 @@ __global__ __launch_bounds__(256) void trsv_pipe_kernel(const float* __restrict_
         const bool last = step == nsteps;               // last pass: multiply by the inverted diagonal block
         if (!last) {
             const int j = TRANSPOSE ? nb - 1 - step : step;
-            if (!wait_flag(&flags[j], ctl, tid, &s_ok)) return;
+            if (!wait_flag(&flags[j], ctl, err_total, tid, &s_ok)) return;
             if (tid < NB) vec[tid] = __hip_atomic_load(&sol[(int64_t)j * NB + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else if (hf == 0) {
             vec[row] = acc;
@@ -615,16 +617,19 @@ int trsv_solve(oisat_ctx* h, const ChFactor& f, double* rhs_pad /* mp, overwritt
     const int nb = (int)(f.mp / NB);
     // control block: [TrsvCtl | flags[nb]] per sweep, two sweeps
     const size_t ctl_bytes = ((sizeof(TrsvCtl) + sizeof(unsigned) * nb + 15) / 16) * 16;
-    char* ctl = (char*)oisat_ws(h, 7, 2 * ctl_bytes);
-    if (!ctl) return OISAT_ENOMEM;
+    // slot 7: [err_total (16 B, cleared by oisat_potrf) | sweep 0 control | sweep 1 control]
+    char* base = (char*)oisat_ws(h, 7, 16 + 2 * ctl_bytes);
+    if (!base) return OISAT_ENOMEM;
+    unsigned* err_total = (unsigned*)base;
+    char* ctl = base + 16;
     HIP_TRY(hipMemsetAsync(ctl, 0, 2 * ctl_bytes, h->stream));
     const size_t shm = sizeof(float) * NB * TLD;
     // forward: L y = rhs   (y -> tmp)
     OISAT_LAUNCH(h, "trsv_fwd", (trsv_pipe_kernel<0>), dim3(nb), dim3(256), shm, f.S, f.ld, (const float*)f.tinv, nb,
-                 (const double*)rhs_pad, tmp, (unsigned*)(ctl + sizeof(TrsvCtl)), (TrsvCtl*)ctl);
+                 (const double*)rhs_pad, tmp, (unsigned*)(ctl + sizeof(TrsvCtl)), (TrsvCtl*)ctl, err_total);
     // backward: L^T z = y  (z -> rhs_pad)
     OISAT_LAUNCH(h, "trsv_bwd", (trsv_pipe_kernel<1>), dim3(nb), dim3(256), shm, f.S, f.ld, (const float*)f.tinv, nb,
-                 (const double*)tmp, rhs_pad, (unsigned*)(ctl + ctl_bytes + sizeof(TrsvCtl)), (TrsvCtl*)(ctl + ctl_bytes));
+                 (const double*)tmp, rhs_pad, (unsigned*)(ctl + ctl_bytes + sizeof(TrsvCtl)), (TrsvCtl*)(ctl + ctl_bytes), err_total);
     return OISAT_OK;
 }
 
@@ -675,6 +680,12 @@ extern "C" int oisat_potrf(oisat_ctx* h, float* S, int64_t m, int64_t ld, int* i
         attr_set = true;
     }
     HIP_TRY(hipMemsetAsync(info_dev, 0, sizeof(int), h->stream));
+    {
+        const size_t ctl_bytes = ((sizeof(TrsvCtl) + sizeof(unsigned) * mpb + 15) / 16) * 16;
+        char* base = (char*)oisat_ws(h, 7, 16 + 2 * ctl_bytes);
+        if (!base) return OISAT_ENOMEM;
+        HIP_TRY(hipMemsetAsync(base, 0, 16, h->stream));      // triangular-solve time-out counter
+    }
     if (mp > m) {
         OISAT_LAUNCH(h, "pad_identity", pad_identity_kernel, dim3(stream_grid((mp - m) * mp, 256)), dim3(256), 0, S, ld, m, mp);
     }
@@ -746,6 +757,13 @@ extern "C" int oisat_gain_solve(oisat_ctx* h, const float* L, const double* oxyz
             HIP_TRY(hipMemcpyAsync(pin, nrm_dev, sizeof(double), hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(hipStreamSynchronize(h->stream));
             resid_host[it] = sqrt(pin[0]) / dnorm;
+            unsigned* pe = (unsigned*)(pin + 8);
+            HIP_TRY(hipMemcpyAsync(pe, h->ws[7], sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            if (*pe != 0) {
+                oisat_set_error("triangular solve: %u workgroup(s) gave up waiting for a predecessor (bounded spin)", *pe);
+                return OISAT_EHIP;
+            }
         }
         if (it == refine) break;
         rc = oisat_potrs(h, L, m, ld, r);
