@@ -55,6 +55,8 @@ struct oisat_ctx {
     // the factor left by the last oisat_potrf on this handle (dense_chol.hip)
     ChFactor factor;
     hipStream_t own_stream = nullptr;   // created by oisat_stream_create, destroyed at shutdown
+    hipStream_t aux_stream = nullptr;   // look-ahead Cholesky: trailing updates run here, the panel chain on `stream`
+    std::vector<hipEvent_t> sync_events;
     // pinned host scratch for small synchronous read-backs
     void* pinned = nullptr;
     size_t pinned_bytes = 0;

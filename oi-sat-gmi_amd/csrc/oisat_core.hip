@@ -52,6 +52,8 @@ extern "C" void oisat_shutdown(oisat_ctx* h) {
         if (h->ws[i]) (void)hipFree(h->ws[i]);
     if (h->pinned) (void)hipHostFree(h->pinned);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
+    for (auto ev : h->sync_events) (void)hipEventDestroy(ev);
     delete h;
 }
 

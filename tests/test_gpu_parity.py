@@ -574,6 +574,39 @@ def test_dense_pieces_through_the_c_abi(ctx):
     assert info.value == 201
 
 
+@pytest.mark.parametrize("schedule", ["recursive", "lookahead"])
+def test_both_cholesky_schedules(ctx, schedule, monkeypatch):
+    """The two schedules of oisat_potrf (recursive: large matrices; two-stream look-ahead: cache-sized ones)
+    on the same ragged matrix: L L^T = S, same solution."""
+    monkeypatch.setenv("OISAT_POTRF", schedule)
+    lib = ctx.lib
+    p, cell = _dense_case(72, 144, 1500, 4242)
+    m, L = 1500, 500.0
+    mp = -(-m // 128) * 128
+    sb = np.sqrt(p.Sa.ravel())
+    po = orc.unit_vectors(p.obs_lat, p.obs_lon)
+    S_ref = orc.gaussian_corr(po, po, L) * sb[cell][:, None] * sb[cell][None, :]
+    S_ref[np.diag_indices(m)] += p.obs_var
+    oxyz = ctx.upload(dense.unit_vectors(p.obs_lat, p.obs_lon))
+    osig = ctx.upload(sb[cell], dtype=np.float64)
+    ovar = ctx.upload(p.obs_var, dtype=np.float64)
+    S = ctx.alloc(mp * mp * 4)
+    for rep in range(3):                                   # repeated calls reuse the events / aux stream
+        ctx.check(lib.oisat_cov_build(ctx.h, oxyz.ptr, osig.ptr, ovar.ptr, m, dense.decay_constant(L), S.ptr, mp))
+        info = C.c_int(-1)
+        ctx.check(lib.oisat_potrf(ctx.h, S.ptr, m, mp, C.byref(info)))
+        assert info.value == 0
+        Lh = np.tril(ctx.download(S.ptr, (mp, mp), np.float32)[:m, :m]).astype(np.float64)
+        rel = np.linalg.norm(Lh @ Lh.T - S_ref) / np.linalg.norm(S_ref)
+        assert rel < 5e-7, (schedule, rep, rel)
+    rhs = np.random.default_rng(1).normal(size=m)
+    zb = ctx.upload(rhs)
+    ctx.check(lib.oisat_potrs(ctx.h, S.ptr, m, mp, zb.ptr))
+    z = ctx.download(zb.ptr, (m,), np.float64)
+    zr = np.linalg.solve(S_ref, rhs)
+    assert np.linalg.norm(z - zr) / np.linalg.norm(zr) < 2e-3
+
+
 def test_dense_reduces_to_elementwise_oi_in_the_limit(ctx, golden):
     """L -> 0, H = cell selection: the dense path must reproduce the REFERENCE's OI at observed cells."""
     g = golden("oi_72x144.npz")
