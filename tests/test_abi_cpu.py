@@ -90,3 +90,18 @@ def test_missing_library_is_loud(monkeypatch, tmp_path):
     monkeypatch.setattr(_hip, "_lib", None)
     with pytest.raises(_hip.OisatUnavailable):
         _hip.load_library()
+
+
+def test_header_is_plain_c_and_a_c_client_links(lib_path, tmp_path):
+    """include/oisat.h must be usable from C (not only C++): compile and link a C99 client against the library."""
+    src = os.path.join(ROOT, "tests", "c", "abi_smoke.c")
+    exe = str(tmp_path / "abi_smoke")
+    libdir = os.path.dirname(lib_path)
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), src, "-o", exe,
+                        "-L", libdir, "-loisat_hip", "-lm", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    import torch
+    if not torch.cuda.is_available():          # no GPU here: the client must fail loudly in oisat_init, not crash
+        run = subprocess.run([exe], capture_output=True, text=True)
+        assert run.returncode == 1 and "oisat_init" in run.stderr

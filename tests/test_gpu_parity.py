@@ -845,3 +845,15 @@ def test_c_abi_rejects_bad_arguments(ctx):
     d = other.upload(np.arange(8.0))
     np.testing.assert_array_equal(other.download(d.ptr, (8,), np.float64), np.arange(8.0))
     other.close()
+
+
+def test_plain_c_client_runs_on_the_gpu(ctx, tmp_path):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = _hip.library_path()
+    exe = str(tmp_path / "abi_smoke")
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c", "abi_smoke.c"), "-o", exe,
+                    "-L", os.path.dirname(lib), "-loisat_hip", "-lm", "-Wl,-rpath," + os.path.dirname(lib), "-Wl,-rpath,/opt/rocm/lib"],
+                   check=True)
+    run = subprocess.run([exe], capture_output=True, text=True)
+    assert run.returncode == 0 and "C ABI smoke ok" in run.stdout, run.stdout + run.stderr
