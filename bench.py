@@ -177,7 +177,7 @@ def tiled_leg(ctx, workload, sync):
 def regrid_leg(ctx, sync):
     """One OMI-NO2-like granule (1644 x 60 pixels, 35 scattering-weight + 35 pressure levels, vcd, amf,
     uncertainty = 73 fields) regridded onto a 0.25 deg global model grid through the drop-in
-    interpolator() (host arrays in, host arrays out), nearest-neighbour type 4 and Delaunay type 1.
+    interpolator() (host arrays in, host arrays out): nearest-neighbour type 4, Delaunay type 1, RBF type 3.
     The reference does one k-d tree build + query and one evaluation PER FIELD (interpolator.py:162-209)."""
     from oisatgmi import synthetic as syn
     from oisatgmi.interpolator import interpolator, _plan_cache
@@ -190,7 +190,7 @@ def regrid_leg(ctx, sync):
     ctm = syn.regional_ctm_grid(-89.875, 89.875, -179.875, 179.875, 0.25, 0.25)
     out = {"workload": "interpolator(): 98,640-pixel granule, 73 fields -> 0.25 deg global grid (720x1440), float64, host in/out"}
     import contextlib, io
-    for it in (4, 1):
+    for it in (4, 1, 3):
         _plan_cache.clear()
         with contextlib.redirect_stdout(io.StringIO()):
             interpolator(it, 0.25, g, ctm, 0.75)                      # warm-up (allocations, plan cache)

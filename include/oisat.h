@@ -161,6 +161,18 @@ int oisat_linear_interp(oisat_ctx* h, int dtype, const double* tlon, const doubl
                         const int32_t* neighbors, const double* transform, int64_t nsimplex,
                         const void* values, int64_t P, int nfields, void* out);
 
+/* RBFInterpolator(points, values, neighbors=5)(targets) for nfields stacked fields (_interpolosis type 3,
+ * interpolator.py:21-27): thin-plate-spline kernel, degree-1 polynomial tail, no smoothing; per target the
+ * `neighbors` (3..5, = min(5, P) in scipy) nearest points, ids sorted ascending, one (neighbors+3)^2 system
+ * solved in double.  nn_idx: nearest point per target from oisat_nn_query with max_dist = cell (the mask
+ * radius 2*threshold); targets with nn_idx < 0 are NaN after the reference's mask and are skipped.  A NaN
+ * value makes every target whose neighbourhood holds it NaN (as dgesv does).  *n_singular (host, may be
+ * NULL) = number of targets whose system had a zero pivot (scipy raises LinAlgError("Singular matrix"));
+ * those targets are written NaN.  Synchronises internally. */
+int oisat_rbf_interp(oisat_ctx* h, int dtype, const double* plon, const double* plat, int64_t P,
+                     const double* tlon, const double* tlat, int64_t T, const int32_t* nn_idx, double cell,
+                     int neighbors, const void* values, int nfields, void* out, int64_t* n_singular);
+
 /* _upscaler fused (interpolator.py:72-91): box-average of the ky*kx window around fine node
  * idx[t] (symmetric boundary, NaN-poisoning, optional variance kernel), evaluated only at the
  * fine nodes the model cells pick; idx < 0 -> NaN.  Z: dev nfields*Ny*Nx; out: dev nfields*T. */

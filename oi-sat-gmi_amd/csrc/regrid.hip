@@ -263,6 +263,182 @@ __global__ __launch_bounds__(256) void linear_interp_kernel(const double* __rest
     }
 }
 
+// ---- local thin-plate-spline RBF (interpolator type 3) ----------------------------------------------
+// RBFInterpolator(points, values, neighbors=5)(targets), interpolator.py:21-27: for every target the K
+// nearest points (ids sorted ascending, as scipy sorts them), the (K+3)x(K+3) system
+//     [ tps(|y_i - y_j|)   1  xhat_i  yhat_i ] [c]   [d]
+//     [ 1 xhat yhat (transposed)    0        ] [ ] = [0]        tps(r) = r^2 log r,  tps(0) = 0
+// on neighbourhood coordinates shifted/scaled to [-1, 1], and out = [tps(|x - y_i|), 1, xhat, yhat] . c.
+// scipy factors each distinct neighbourhood with LAPACK dgesv in a Python loop.  Here one thread owns a
+// target: it finds its K neighbours by expanding rings of the point hash until the K-th distance is
+// inside the searched square, factors the symmetric system once with partially pivoted LU held in
+// registers, solves for the evaluation weights w = A^-1 vec (A is symmetric, so out = w[:K] . d) and
+// applies them to every stacked field.  A NaN value poisons its neighbourhood exactly as a NaN
+// right-hand side poisons dgesv's coefficients.  A zero pivot is LAPACK's info > 0: counted, NaN written.
+// Targets whose nearest point is beyond the mask radius (nn_idx < 0) are skipped: NaN after the mask anyway.
+__device__ __forceinline__ double tps(double r2) {      // r^2 log r with r = sqrt(r2), evaluated as scipy does
+    const double r = sqrt(r2);
+    return r == 0.0 ? 0.0 : (r * r) * log(r);
+}
+
+template <typename T, int K>
+__global__ __launch_bounds__(64) void rbf_interp_kernel(const double* __restrict__ px, const double* __restrict__ py,
+                                                         const double* __restrict__ tx, const double* __restrict__ ty, int64_t Tn,
+                                                         const int32_t* __restrict__ nn_idx, HashGrid g,
+                                                         const unsigned* __restrict__ start, const int32_t* __restrict__ sorted,
+                                                         const T* __restrict__ values, int64_t P, int nfields, T* __restrict__ out,
+                                                         int* __restrict__ n_singular) {
+    constexpr int N = K + 3;
+    const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (t >= Tn) return;
+    bool ok = nn_idx[t] >= 0;
+    const double x = tx[t], y = ty[t];
+    ok = ok && x == x && y == y;
+    double bd[K];
+    int32_t id[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) { bd[q] = __builtin_inf(); id[q] = -1; }
+    if (ok) {
+        int cx, cy;
+        cell_of(g, x, y, cx, cy);
+        const double hcell = 1.0 / g.inv_h;
+        int rlast = cx > cy ? cx : cy;                       // ring beyond which every cell has been visited
+        if (g.nbx - 1 - cx > rlast) rlast = g.nbx - 1 - cx;
+        if (g.nby - 1 - cy > rlast) rlast = g.nby - 1 - cy;
+        for (int r = 0; r <= rlast; ++r) {
+            for (int yy = cy - r; yy <= cy + r; ++yy) {
+                if (yy < 0 || yy >= g.nby) continue;
+                const bool edge_row = (yy == cy - r) || (yy == cy + r);
+                const int step = edge_row ? 1 : (2 * r > 0 ? 2 * r : 1);      // interior rows: only the two end cells
+                for (int xx = cx - r; xx <= cx + r; xx += step) {
+                    if (xx < 0 || xx >= g.nbx) continue;
+                    const int c = yy * g.nbx + xx;
+                    for (unsigned s = start[c]; s < start[c + 1]; ++s) {
+                        const int32_t i = sorted[s];
+                        const double dx = px[i] - x, dy = py[i] - y;
+                        const double d2 = dx * dx + dy * dy;
+                        if (d2 < bd[K - 1] || (d2 == bd[K - 1] && i < id[K - 1])) {
+                            bd[K - 1] = d2;
+                            id[K - 1] = i;
+#pragma unroll
+                            for (int q = K - 1; q > 0; --q) {
+                                const bool sw = bd[q] < bd[q - 1] || (bd[q] == bd[q - 1] && id[q] < id[q - 1]);
+                                const double td = bd[q];
+                                const int32_t ti = id[q];
+                                bd[q] = sw ? bd[q - 1] : td;
+                                id[q] = sw ? id[q - 1] : ti;
+                                bd[q - 1] = sw ? td : bd[q - 1];
+                                id[q - 1] = sw ? ti : id[q - 1];
+                            }
+                        }
+                    }
+                }
+            }
+            // every unvisited point lies at least r cells away along one axis
+            const double reach = r * hcell * (1.0 - 1e-12);
+            if (id[K - 1] >= 0 && bd[K - 1] < reach * reach) break;
+        }
+        ok = id[K - 1] >= 0;
+    }
+    bool singular = false;
+    double w[N];
+    if (ok) {
+#pragma unroll
+        for (int a = 0; a < K - 1; ++a)                       // ids ascending (np.sort(yindices, axis=1))
+#pragma unroll
+            for (int q = 0; q < K - 1 - a; ++q) {
+                const int32_t lo = id[q] < id[q + 1] ? id[q] : id[q + 1];
+                const int32_t hi = id[q] < id[q + 1] ? id[q + 1] : id[q];
+                id[q] = lo;
+                id[q + 1] = hi;
+            }
+        double yx[K], yy[K];
+        double xmin = __builtin_inf(), xmax = -__builtin_inf(), ymin = __builtin_inf(), ymax = -__builtin_inf();
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+            yx[q] = px[id[q]];
+            yy[q] = py[id[q]];
+            xmin = fmin(xmin, yx[q]); xmax = fmax(xmax, yx[q]);
+            ymin = fmin(ymin, yy[q]); ymax = fmax(ymax, yy[q]);
+        }
+        const double shx = (xmax + xmin) / 2, shy = (ymax + ymin) / 2;
+        double scx = (xmax - xmin) / 2, scy = (ymax - ymin) / 2;
+        if (scx == 0.0) scx = 1.0;
+        if (scy == 0.0) scy = 1.0;
+        double a[N][N + 1];                                    // [A | vec]
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const double dx = yx[i] - yx[j], dy = yy[i] - yy[j];
+                a[i][j] = (i == j) ? 0.0 : tps(dx * dx + dy * dy);
+            }
+            a[i][K] = 1.0;
+            a[i][K + 1] = (yx[i] - shx) / scx;
+            a[i][K + 2] = (yy[i] - shy) / scy;
+            a[K][i] = 1.0;
+            a[K + 1][i] = a[i][K + 1];
+            a[K + 2][i] = a[i][K + 2];
+            const double dx = x - yx[i], dy = y - yy[i];
+            a[i][N] = tps(dx * dx + dy * dy);
+        }
+#pragma unroll
+        for (int i = K; i < N; ++i)
+#pragma unroll
+            for (int j = K; j < N; ++j) a[i][j] = 0.0;
+        a[K][N] = 1.0;
+        a[K + 1][N] = (x - shx) / scx;
+        a[K + 2][N] = (y - shy) / scy;
+        // LU with partial pivoting (first largest |.|, as idamax), augmented column carried along
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            int p = k;
+            double pm = fabs(a[k][k]);
+#pragma unroll
+            for (int i = k + 1; i < N; ++i) {
+                const double v = fabs(a[i][k]);
+                if (v > pm) { pm = v; p = i; }
+            }
+            if (!(pm > 0.0)) singular = true;
+#pragma unroll
+            for (int i = k + 1; i < N; ++i) {
+                const bool sw = (i == p);
+#pragma unroll
+                for (int j = k; j <= N; ++j) {
+                    const double u = a[i][j], v = a[k][j];
+                    a[i][j] = sw ? v : u;
+                    a[k][j] = sw ? u : v;
+                }
+            }
+            const double inv = 1.0 / a[k][k];
+#pragma unroll
+            for (int i = k + 1; i < N; ++i) {
+                const double l = a[i][k] * inv;
+#pragma unroll
+                for (int j = k + 1; j <= N; ++j) a[i][j] -= l * a[k][j];
+            }
+        }
+#pragma unroll
+        for (int i = N - 1; i >= 0; --i) {
+            double sacc = a[i][N];
+#pragma unroll
+            for (int j = i + 1; j < N; ++j) sacc -= a[i][j] * w[j];
+            w[i] = sacc / a[i][i];
+        }
+        if (singular) atomicAdd(n_singular, 1);
+    }
+    for (int f = 0; f < nfields; ++f) {
+        double o = __builtin_nan("");
+        if (ok && !singular) {
+            const T* vf = values + (int64_t)f * P;
+            o = 0.0;
+#pragma unroll
+            for (int q = 0; q < K; ++q) o += w[q] * (double)vf[id[q]];
+        }
+        out[(int64_t)f * Tn + t] = (T)o;
+    }
+}
+
 }  // namespace
 
 extern "C" int oisat_boxfilter_symm(oisat_ctx* h, int dtype, const void* Z, int64_t Ny, int64_t Nx, int ky, int kx, int variance,
@@ -388,10 +564,10 @@ __global__ __launch_bounds__(256) void minmax_kernel(const double* __restrict__ 
         for (int q = 0; q < 4; ++q) out[blockIdx.x * 4 + q] = sm[q][0];
 }
 
-extern "C" int oisat_nn_query(oisat_ctx* h, const double* plon, const double* plat, int64_t P, const double* tlon,
-                              const double* tlat, int64_t Tn, double max_dist, int32_t* idx_out, double* dist_out) {
-    ARG_CHECK(h && plon && plat && tlon && tlat && idx_out);
-    ARG_CHECK(P > 0 && P < (int64_t)INT32_MAX && Tn > 0 && max_dist > 0.0 && std::isfinite(max_dist));
+// Hash the points into uniform cells of edge `cell` (coarsened if that would need too many cells).
+// On return start[c]..start[c+1] index `sorted` (point ids of cell c); both live in workspace slot 2.
+static int build_hash(oisat_ctx* h, const double* plon, const double* plat, int64_t P, double cell, HashGrid* g_out,
+                      const unsigned** start_out, const int32_t** sorted_out) {
     // 1. bounding box of the points
     const int mm_blocks = 64;
     double* mm_dev = (double*)oisat_ws(h, 1, sizeof(double) * 4 * mm_blocks);
@@ -406,8 +582,7 @@ extern "C" int oisat_nn_query(oisat_ctx* h, const double* plon, const double* pl
         ymin = fmin(ymin, mm_host[b * 4 + 2]); ymax = fmax(ymax, mm_host[b * 4 + 3]);
     }
     // (no finite point at all -> a 1x1 empty grid below: every target comes back -1 / +inf)
-    // 2. hash grid with cell edge = mask radius (coarsened if that would need too many cells)
-    double cell = max_dist;
+    // 2. hash grid
     const double spanx = (xmin <= xmax) ? xmax - xmin : 0.0, spany = (ymin <= ymax) ? ymax - ymin : 0.0;
     const int64_t max_cells = 4 * 1024 * 1024;
     while ((floor(spanx / cell) + 1.0) * (floor(spany / cell) + 1.0) > (double)max_cells) cell *= 2.0;
@@ -437,8 +612,69 @@ extern "C" int oisat_nn_query(oisat_ctx* h, const double* plon, const double* pl
     OISAT_LAUNCH(h, "nn_scan", nn_scan_kernel, dim3(1), dim3(1024), 0, (const unsigned*)counts, ncell, start, cursor);
     OISAT_LAUNCH(h, "nn_scatter", nn_scatter_kernel, dim3(stream_grid(P, 256)), dim3(256), 0, (const int32_t*)pcell, P, cursor,
                  sorted);
-    OISAT_LAUNCH(h, "nn_query", nn_query_kernel, dim3(stream_grid(Tn, 256)), dim3(256), 0, plon, plat, tlon, tlat, Tn, g,
-                 (const unsigned*)start, (const int32_t*)sorted, max_dist, idx_out, dist_out);
+    *g_out = g;
+    *start_out = start;
+    *sorted_out = sorted;
+    return OISAT_OK;
+}
+
+extern "C" int oisat_nn_query(oisat_ctx* h, const double* plon, const double* plat, int64_t P, const double* tlon,
+                              const double* tlat, int64_t Tn, double max_dist, int32_t* idx_out, double* dist_out) {
+    ARG_CHECK(h && plon && plat && tlon && tlat && idx_out);
+    ARG_CHECK(P > 0 && P < (int64_t)INT32_MAX && Tn > 0 && max_dist > 0.0 && std::isfinite(max_dist));
+    // cell edge = mask radius: the 3x3 block around a target holds every candidate that can survive the mask
+    HashGrid g;
+    const unsigned* start;
+    const int32_t* sorted;
+    const int rc = build_hash(h, plon, plat, P, max_dist, &g, &start, &sorted);
+    if (rc != OISAT_OK) return rc;
+    OISAT_LAUNCH(h, "nn_query", nn_query_kernel, dim3(stream_grid(Tn, 256)), dim3(256), 0, plon, plat, tlon, tlat, Tn, g, start,
+                 sorted, max_dist, idx_out, dist_out);
+    return OISAT_OK;
+}
+
+template <typename T>
+static int rbf_launch(oisat_ctx* h, int K, const double* plon, const double* plat, const double* tlon, const double* tlat,
+                      int64_t Tn, const int32_t* nn_idx, HashGrid g, const unsigned* start, const int32_t* sorted, const void* values,
+                      int64_t P, int nfields, void* out, int* flag) {
+    const dim3 grid((unsigned)cdiv(Tn, 64)), block(64);
+    if (K == 5) {
+        OISAT_LAUNCH(h, "rbf_interp", (rbf_interp_kernel<T, 5>), grid, block, 0, plon, plat, tlon, tlat, Tn, nn_idx, g, start, sorted,
+                     (const T*)values, P, nfields, (T*)out, flag);
+    } else if (K == 4) {
+        OISAT_LAUNCH(h, "rbf_interp", (rbf_interp_kernel<T, 4>), grid, block, 0, plon, plat, tlon, tlat, Tn, nn_idx, g, start, sorted,
+                     (const T*)values, P, nfields, (T*)out, flag);
+    } else {
+        OISAT_LAUNCH(h, "rbf_interp", (rbf_interp_kernel<T, 3>), grid, block, 0, plon, plat, tlon, tlat, Tn, nn_idx, g, start, sorted,
+                     (const T*)values, P, nfields, (T*)out, flag);
+    }
+    return OISAT_OK;
+}
+
+extern "C" int oisat_rbf_interp(oisat_ctx* h, int dtype, const double* plon, const double* plat, int64_t P, const double* tlon,
+                                const double* tlat, int64_t Tn, const int32_t* nn_idx, double cell, int neighbors,
+                                const void* values, int nfields, void* out, int64_t* n_singular) {
+    ARG_CHECK(h && plon && plat && tlon && tlat && nn_idx && values && out);
+    ARG_CHECK(P >= 3 && P < (int64_t)INT32_MAX && Tn > 0 && nfields > 0 && cell > 0.0 && std::isfinite(cell));
+    ARG_CHECK(neighbors >= 3 && neighbors <= 5 && neighbors <= P);
+    ARG_CHECK(dtype == OISAT_F32 || dtype == OISAT_F64);
+    HashGrid g;
+    const unsigned* start;
+    const int32_t* sorted;
+    int rc = build_hash(h, plon, plat, P, cell, &g, &start, &sorted);
+    if (rc != OISAT_OK) return rc;
+    int* flag = (int*)oisat_ws(h, 1, 64);
+    int* flag_host = (int*)oisat_pinned(h, 64);
+    if (!flag || !flag_host) return OISAT_ENOMEM;
+    HIP_TRY(hipMemsetAsync(flag, 0, 64, h->stream));
+    if (dtype == OISAT_F32)
+        rc = rbf_launch<float>(h, neighbors, plon, plat, tlon, tlat, Tn, nn_idx, g, start, sorted, values, P, nfields, out, flag);
+    else
+        rc = rbf_launch<double>(h, neighbors, plon, plat, tlon, tlat, Tn, nn_idx, g, start, sorted, values, P, nfields, out, flag);
+    if (rc != OISAT_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(flag_host, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (n_singular) *n_singular = flag_host[0];
     return OISAT_OK;
 }
 

@@ -1,8 +1,8 @@
 """Swath -> model-grid regridding on the MI355X.
 
 Drop-in for ``oisatgmi/interpolator.py`` of the reference (``interpolator``, ``_upscaler``,
-``_interpolosis``, ``_boxfilter``, ``_boxfilter2``), nearest-neighbour interpolator types
-(2 and 4).  What changes underneath:
+``_interpolosis``, ``_boxfilter``, ``_boxfilter2``), all four interpolator types.  What changes
+underneath (nearest-neighbour types 2 and 4 first):
 
 * the reference builds a k-d tree over the ~1e6 fine-grid nodes inside EVERY ``_upscaler`` call
   and re-queries the swath tree for every field (interpolator.py:78-88, :28-33).  Here the two
@@ -17,8 +17,11 @@ Type 1 (Delaunay linear, the reference's "recommended" default): the triangulati
 qhull on the host exactly as the reference does (``Delaunay(points)``, interpolator.py:153); point
 location and barycentric evaluation -- what ``LinearNDInterpolator`` repeats for every field -- run
 on the device for all stacked fields at once (``oisat_linear_interp``).
-Type 3 (RBF) is not implemented on the device and raises ``NotImplementedError`` -- there is no
-silent CPU path.
+Type 3 (``RBFInterpolator(points, Z, neighbors=5)``: thin-plate spline on the 5 nearest pixels): the
+reference solves one 8x8 system per distinct neighbourhood in a Python loop, for every field; here one
+thread per target finds its neighbours, factors the system once and applies the evaluation weights to
+every stacked field (``oisat_rbf_interp``).  Targets the distance mask removes anyway are skipped, so
+a singular neighbourhood raises ``LinAlgError`` only when it feeds an unmasked target.
 """
 from __future__ import annotations
 
@@ -134,6 +137,21 @@ class TriIndex:
         return out
 
 
+def _rbf(nn: "NNIndex", dt, values_buf, nfields, tgt_buf, T, idx_buf, cell):
+    """``RBFInterpolator(points, values, neighbors=5)`` at the targets whose nearest point lies within ``cell``."""
+    ctx = nn.ctx
+    if nn.P < 3:                        # scipy: 3 monomials need 3 points
+        raise ValueError("At least 3 data points are required when `degree` is 1 and the number of dimensions is 2.")
+    out = ctx.alloc(nfields * T * dt.itemsize)
+    nsing = _hip.C.c_int64(0)
+    ctx.check(ctx.lib.oisat_rbf_interp(ctx.h, _hip.dtype_code(dt), nn.buf.at(0), nn.buf.at(nn.P * 8), nn.P, tgt_buf.at(0),
+                                       tgt_buf.at(T * 8), T, idx_buf.ptr, float(cell), int(min(5, nn.P)), values_buf.ptr,
+                                       nfields, out.ptr, _hip.C.byref(nsing)))
+    if nsing.value:
+        raise np.linalg.LinAlgError("Singular matrix.")
+    return out
+
+
 def _gather(ctx, dt, values_buf, P, nfields, idx_buf, T):
     out = ctx.alloc(nfields * T * dt.itemsize)
     ctx.check(ctx.lib.oisat_gather_mask(ctx.h, _hip.dtype_code(dt), values_buf.ptr, P, nfields, idx_buf.ptr, T, out.ptr))
@@ -142,12 +160,24 @@ def _gather(ctx, dt, values_buf, P, nfields, idx_buf, T):
 
 def _interpolosis(interpol_func, Z: np.ndarray, X: np.ndarray, Y: np.ndarray, interpolator_type: int,
                   dists: np.ndarray, threshold: float) -> np.ndarray:
-    """One field, host in / host out (interpolator.py:10-37), types 1, 2 and 4."""
-    if interpolator_type == 3:
-        raise NotImplementedError("interpolator_type 3 (RBF) is not implemented in the HIP backend (types 1, 2 and 4 are)")
-    if interpolator_type not in (1, 2, 4):
+    """One field, host in / host out (interpolator.py:10-37)."""
+    if interpolator_type not in (1, 2, 3, 4):
         raise Exception("other type of interpolation methods has not been implemented yet")
     ctx = _hip.context()
+    if interpolator_type == 3:          # interpol_func: the (P, 2) point array (interpolator.py:156-157)
+        nn = NNIndex.from_any(interpol_func)
+        dt = _hip.compute_dtype(Z)
+        Zb = ctx.upload(np.ravel(Z), dtype=dt)
+        T = int(np.size(X))
+        tb = ctx.alloc(2 * T * 8)
+        ctx.upload_into(tb.at(0), np.ravel(X), dtype=np.float64)
+        ctx.upload_into(tb.at(T * 8), np.ravel(Y), dtype=np.float64)
+        cell = 2.0 * float(threshold)
+        idx, _ = nn.query_device(X, Y, cell)
+        out = _rbf(nn, dt, Zb, 1, tb, T, idx, cell)
+        ZZ = ctx.download(out.ptr, np.shape(X), dt)
+        ZZ[np.asarray(dists) > threshold * 2.0] = np.nan
+        return ZZ
     if interpolator_type == 1:
         ti = interpol_func if isinstance(interpol_func, TriIndex) else TriIndex(interpol_func)     # a scipy Delaunay
         pts = ti.tri.points
@@ -287,11 +317,12 @@ class _GranuleRegridder:
         self.swath_shape = np.shape(np.squeeze(sat_data.quality_flag))
         self.flag_thresh = float(flag_thresh)
         self.qflag_host = np.squeeze(sat_data.quality_flag)
-        nn = NNIndex(sat_data.longitude_center, sat_data.latitude_center)
-        self.idx_fine, _ = nn.query_device(self.lons_grid, self.lats_grid, 2.0 * float(grid_size))   # :145-150,:16-33
+        self.nn = nn = NNIndex(sat_data.longitude_center, sat_data.latitude_center)
+        self.cell = 2.0 * float(grid_size)
+        self.idx_fine, _ = nn.query_device(self.lons_grid, self.lats_grid, self.cell)   # :145-150,:16-33
         self.plan = _upscale_plan(self.lons_grid, self.lats_grid, ctm_models_coordinate, grid_size, threshold_ctm)
         self._flag_bufs = {}
-        if self.kind == 1:
+        if self.kind in (1, 3):
             self.tgt = ctx.alloc(2 * self.Tfine * 8)
             ctx.upload_into(self.tgt.at(0), np.ravel(self.lons_grid), dtype=np.float64)
             ctx.upload_into(self.tgt.at(self.Tfine * 8), np.ravel(self.lats_grid), dtype=np.float64)
@@ -325,6 +356,8 @@ class _GranuleRegridder:
                                               0, masked.at(f * self.P * item)))
         if self.kind == 1:               # targets beyond 2*grid_size of any pixel carry idx -1 -> NaN, like the dists mask
             fine = self.tri.interpolate(dt, masked, nf, self.tgt, self.Tfine, self.idx_fine)
+        elif self.kind == 3:
+            fine = _rbf(self.nn, dt, masked, nf, self.tgt, self.Tfine, self.idx_fine, self.cell)
         else:
             fine = _gather(ctx, dt, masked, self.P, nf, self.idx_fine, self.Tfine)
         if self.plan.needed:
@@ -346,16 +379,14 @@ def interpolator(interpolator_type: int, grid_size: float, sat_data, ctm_models_
             interpolator_type [int]: an index specifying the type of interpolator
                     1 > Bilinear interpolation (Delaunay, recommended)
                     2 > Nearest neighbour
-                    3 > RBF (thin_plate_spline) (not on the device yet)
+                    3 > RBF (thin_plate_spline)
                     4 > KDtree (fast nearest neighbour)
             grid_size [float]: the size of grids defined by the user
             sat_data  [satellite_amf or satellite_opt]: a dataclass for satellite data
             ctm_models_coordinate [dic]: a dictionary containing lat and lon of the model
             flag_thresh [float]: the quality flag threshold
     '''
-    if interpolator_type == 3:
-        raise NotImplementedError("interpolator_type 3 (RBF) is not implemented in the HIP backend (types 1, 2 and 4 are)")
-    if interpolator_type not in (1, 2, 4):
+    if interpolator_type not in (1, 2, 3, 4):
         raise Exception("other type of interpolation methods has not been implemented yet")
     rg = _GranuleRegridder(sat_data, grid_size, ctm_models_coordinate, flag_thresh, interpolator_type)
     if not rg.ok:

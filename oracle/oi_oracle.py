@@ -9,7 +9,7 @@ library is missing instead of falling back to anything in here.
 Pinning status ("Oracle"):
 
 * ``OI`` (fixed index), the 99-point regularisation curve, ``error_averager``, ``averaging``,
-  ``_upscaler``, ``_interpolosis`` types 2/4 and ``interpolator`` (2-D field path) are PINNED:
+  ``_upscaler``, ``_interpolosis`` types 1-4 and ``interpolator`` (2-D field path) are PINNED:
   ``tests/golden/*.npz`` hold outputs of the reference's own functions, produced in the build
   container by ``tests/golden/make_golden.py`` importing the reference modules.
 * The knee index chosen from that curve comes from the third-party package ``kneed==0.8.3``
@@ -264,6 +264,65 @@ def interpolosis_nn(tree: _cKDTree, Z, X, Y, dists, threshold):
     return ZZ
 
 
+def _tps(r):
+    """thin-plate spline r^2 log r (0 at r = 0), scipy's default RBFInterpolator kernel"""
+    with np.errstate(all="ignore"):
+        return np.where(r == 0.0, 0.0, r * r * np.log(r))
+
+
+def interpolosis_rbf(pts, Z, X, Y, dists, threshold, neighbors=5, only_unmasked=False):
+    """``_interpolosis`` type 3 (interpolator.py:21-27): ``RBFInterpolator(points, Z.flatten(),
+    neighbors=5)`` -- thin-plate-spline kernel, degree-1 polynomial tail, no smoothing (scipy
+    1.11/1.15 ``_rbfinterp.py``) -- evaluated at every target, then NaN where ``dists > 2*threshold``.
+
+    Per target: the k nearest data points (indices sorted ascending), the (k+3)x(k+3) system
+    ``[[K, P], [P^T, 0]] c = [d, 0]`` with ``K_ij = tps(|y_i - y_j|)`` and ``P = [1, xhat, yhat]`` on
+    coordinates shifted/scaled to [-1, 1] over the neighbourhood, then ``out = [tps(|x - y_i|), 1, xhat,
+    yhat] . c``.  scipy solves each distinct neighbourhood with LAPACK dgesv; this restatement solves
+    all targets as one batch (``np.linalg.solve``), same arithmetic up to rounding.  A singular system
+    raises ``LinAlgError`` like scipy.  ``only_unmasked`` restricts the work (and the singularity check)
+    to targets that survive the mask -- what the HIP backend does."""
+    pts = np.asarray(pts, dtype=np.float64)
+    d = np.asarray(Z, dtype=np.float64).ravel()
+    k = int(min(neighbors, pts.shape[0]))
+    if k < 3:
+        raise ValueError("At least 3 data points are required when `degree` is 1 and the number of dimensions is 2.")
+    tgt = np.column_stack((np.ravel(X), np.ravel(Y))).astype(np.float64)
+    out = np.full(tgt.shape[0], np.nan)
+    keep = ~(np.ravel(dists) > threshold * 2.0) if only_unmasked else np.ones(tgt.shape[0], dtype=bool)
+    if keep.any():
+        x = tgt[keep]
+        _, nb = _cKDTree(pts).query(x, k)
+        nb = np.sort(nb.reshape(x.shape[0], k), axis=1)
+        y = pts[nb]                                                   # (T, k, 2)
+        mins, maxs = y.min(axis=1), y.max(axis=1)
+        shift, scale = (maxs + mins) / 2, (maxs - mins) / 2
+        scale[scale == 0.0] = 1.0
+        yhat = (y - shift[:, None, :]) / scale[:, None, :]
+        xhat = (x - shift) / scale
+        T = x.shape[0]
+        A = np.zeros((T, k + 3, k + 3))
+        A[:, :k, :k] = _tps(np.sqrt(((y[:, :, None, :] - y[:, None, :, :]) ** 2).sum(-1)))
+        A[:, :k, k] = 1.0
+        A[:, :k, k + 1:] = yhat
+        A[:, k:, :k] = np.swapaxes(A[:, :k, k:], 1, 2)
+        rhs = np.zeros((T, k + 3))
+        rhs[:, :k] = d[nb]
+        bad = ~np.isfinite(rhs).all(axis=1)                           # NaN data poison the whole neighbourhood
+        rhs[bad] = 0.0
+        coef = np.linalg.solve(A, rhs[:, :, None])[:, :, 0]           # raises LinAlgError("Singular matrix")
+        vec = np.empty((T, k + 3))
+        vec[:, :k] = _tps(np.sqrt(((x[:, None, :] - y) ** 2).sum(-1)))
+        vec[:, k] = 1.0
+        vec[:, k + 1:] = xhat
+        o = (vec * coef).sum(axis=1)
+        o[bad] = np.nan
+        out[keep] = o
+    ZZ = out.reshape(np.shape(X))
+    ZZ[dists > threshold * 2.0] = np.nan
+    return ZZ
+
+
 def upscaler(X, Y, Z, ctm_models_coordinate, grid_size, threshold, error=False):
     """``_upscaler`` (interpolator.py:48-97)."""
     clat = ctm_models_coordinate["Latitude"]
@@ -287,10 +346,10 @@ def upscaler(X, Y, Z, ctm_models_coordinate, grid_size, threshold, error=False):
 def interpolator(interpolator_type, grid_size, sat_data, ctm_models_coordinate, flag_thresh=0.75,
                  record_type=None):
     """``interpolator`` (interpolator.py:100-291), 2-D field path of a ``satellite_amf`` record
-    (vcd, amf, tropopause if array, uncertainty) for nearest-neighbour types 2 and 4.
+    (vcd, amf, tropopause if array, uncertainty) and its per-level cubes, interpolator types 1-4.
     Returns a ``record_type`` (positional, :289-290) or None."""
-    if interpolator_type not in (1, 2, 4):
-        raise NotImplementedError("oracle covers types 1 (Delaunay linear), 2 and 4 (nearest neighbour)")
+    if interpolator_type not in (1, 2, 3, 4):
+        raise Exception("other type of interpolation methods has not been implemented yet")
     clat = ctm_models_coordinate["Latitude"]
     clon = ctm_models_coordinate["Longitude"]
     dlon = np.abs(clon[0, 0] - clon[0, 1])
@@ -318,6 +377,8 @@ def interpolator(interpolator_type, grid_size, sat_data, ctm_models_coordinate, 
         if tri is not None:                                     # _interpolosis type 1, interpolator.py:12-16
             zz = LinearNDInterpolator(tri, np.asarray(field, dtype=np.float64).flatten(), fill_value=np.nan)((lons, lats))
             zz[dists > grid_size * 2.0] = np.nan
+        elif interpolator_type == 3:
+            zz = interpolosis_rbf(pts, field, lons, lats, dists, grid_size)
         else:
             zz = interpolosis_nn(tree, field, lons, lats, dists, grid_size)
         return upscaler(lons, lats, zz, ctm_models_coordinate, grid_size, threshold_ctm, error=error)

@@ -215,6 +215,33 @@ def gen_interpolator():
     save("interpolator.npz", **out)
 
 
+def gen_interpolator_rbf():
+    """interpolator type 3 (RBFInterpolator, 5 neighbours, thin-plate spline; interpolator.py:21-27), kept in
+    its own file: the reference solves one 8x8 system per distinct neighbourhood in a Python loop."""
+    out = {}
+    g = syn.swath_granule(5005)
+    for tag, (dlat, dlon, gs) in {"fine": (0.25, 0.25, 0.25), "coarse": (2.0, 2.5, 0.25)}.items():
+        ctm = syn.regional_ctm_grid(-30.0, 50.0, -25.0, 45.0, dlat, dlon)
+        r = quiet(REF_interp.interpolator, 3, gs, to_ref(g), ctm, 0.75)
+        assert r is not None
+        for f in ("vcd", "amf", "uncertainty", "latitude_center", "longitude_center"):
+            out[f"{tag}_t3_{f}"] = np.asarray(getattr(r, f))
+        out[f"{tag}_t3_need"] = r.ctm_upscaled_needed
+    # _interpolosis type 3 by itself: scattered targets, a NaN value, distances handed in by the caller
+    rng = np.random.default_rng(3303)
+    pts = np.column_stack((g.longitude_center.ravel(), g.latitude_center.ravel()))
+    Z = g.vcd.copy()
+    Z[17, 23] = np.nan
+    X = rng.uniform(0.0, 20.0, size=(40, 50))
+    Y = rng.uniform(-10.0, 30.0, size=(40, 50))
+    from scipy.spatial import cKDTree
+    dists, _ = cKDTree(pts).query(np.column_stack((X.ravel(), Y.ravel())))
+    dists = dists.reshape(X.shape)
+    out["single_X"], out["single_Y"], out["single_Z"], out["single_dists"] = X, Y, Z, dists
+    out["single_out"] = REF_interp._interpolosis(pts, Z, X, Y, 3, dists, 0.25)
+    save("interpolator_rbf.npz", **out)
+
+
 def amf_cases():
     """name -> (ctm_data, sat_data) builders shared with the tests (seeded)"""
     def case_a():
@@ -268,6 +295,9 @@ def gen_records():
 
 if __name__ == "__main__":
     print("generating golden vectors from", REF)
+    if sys.argv[1:] == ["rbf"]:                   # only the (slow) type-3 file
+        gen_interpolator_rbf()
+        raise SystemExit(0)
     gen_records()
     gen_oi("72x144", 72, 144, 1000, 1001, full=True)
     gen_oi("360x720", 360, 720, 10000, 2001, full=False)
@@ -277,5 +307,6 @@ if __name__ == "__main__":
     gen_averaging()
     gen_upscaler()
     gen_interpolator()
+    gen_interpolator_rbf()
     gen_amf_recal()
     print("done")

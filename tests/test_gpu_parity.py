@@ -426,13 +426,83 @@ def test_interpolator_matches_reference(ctx, golden):
     ctm = syn.regional_ctm_grid(-80.0, -60.0, 100.0, 140.0, 2.0, 2.5)
     assert interpolator(4, 0.25, s, ctm, 0.75) is None
     assert interpolator(1, 0.25, s, ctm, 0.75) is None
-    with pytest.raises(NotImplementedError):
-        interpolator(3, 0.25, s, ctm, 0.75)
+    assert interpolator(3, 0.25, s, ctm, 0.75) is None
+    with pytest.raises(Exception, match="has not been implemented yet"):       # interpolator.py:34-36
+        interpolator(5, 0.25, s, ctm, 0.75)
     # qhull cannot triangulate collinear pixels: the reference returns None for such a granule (:151-155)
     bad = syn.swath_granule(1, nscan=8, npix=1)
     bad.latitude_center = np.linspace(0, 7, 8)[:, None]
     bad.longitude_center = np.linspace(0, 7, 8)[:, None]
     assert interpolator(1, 0.25, bad, syn.regional_ctm_grid(-2.0, 10.0, -2.0, 10.0, 1.0, 1.0), 0.75) is None
+
+
+# thin-plate-spline systems on 5 jittered pixels: the reference (LAPACK dgesv per neighbourhood) and the
+# in-register LU agree to rounding x conditioning; measured 2.4e-14 of the field scale on the golden granule
+RBF_TOL = 1e-11
+
+
+def test_interpolator_type3_rbf_matches_reference(ctx, golden):
+    """interpolator type 3 (interpolator.py:21-27, RBFInterpolator(neighbors=5)) against outputs of the
+    reference's own function (tests/golden/interpolator_rbf.npz), NaN pattern included."""
+    g = golden("interpolator_rbf.npz")
+    s = syn.swath_granule(5005)
+    for tag, (dlat, dlon) in {"fine": (0.25, 0.25), "coarse": (2.0, 2.5)}.items():
+        ctm = syn.regional_ctm_grid(-30.0, 50.0, -25.0, 45.0, dlat, dlon)
+        r = interpolator(3, 0.25, s, ctm, 0.75)
+        assert isinstance(r, cfg.satellite_amf)
+        assert bool(r.ctm_upscaled_needed) == bool(g[f"{tag}_t3_need"])
+        for f in ("vcd", "amf", "uncertainty", "latitude_center", "longitude_center"):
+            want = g[f"{tag}_t3_{f}"]
+            got = np.asarray(getattr(r, f))
+            assert np.array_equal(np.isnan(got), np.isnan(want)), f"{tag} {f}: NaN pattern"
+            np.testing.assert_allclose(got, want, rtol=0, atol=RBF_TOL * np.nanmax(np.abs(want)), equal_nan=True,
+                                       err_msg=f"{tag} type 3 {f}")
+    # _interpolosis by itself: scattered targets, caller-supplied distances
+    pts = np.column_stack((s.longitude_center.ravel(), s.latitude_center.ravel()))
+    got = _interpolosis(pts, g["single_Z"], g["single_X"], g["single_Y"], 3, g["single_dists"], 0.25)
+    want = g["single_out"]
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    np.testing.assert_allclose(got, want, rtol=0, atol=RBF_TOL * np.nanmax(np.abs(want)), equal_nan=True)
+
+
+def test_rbf_edge_cases(ctx):
+    """float32 kernels, fewer than 5 points, a singular (collinear) neighbourhood, a NaN value."""
+    rng = np.random.default_rng(77)
+    pts = rng.uniform(0.0, 4.0, size=(400, 2))
+    Z = np.sin(pts[:, 0]) + pts[:, 1] ** 2
+    X, Y = np.meshgrid(np.linspace(0.5, 3.5, 31), np.linspace(0.5, 3.5, 29))
+    from scipy.spatial import cKDTree
+    d, _ = cKDTree(pts).query(np.column_stack((X.ravel(), Y.ravel())))
+    d = d.reshape(X.shape)
+    want = orc.interpolosis_rbf(pts, Z, X, Y, d, 0.5)
+    got = _interpolosis(pts, Z, X, Y, 3, d, 0.5)
+    np.testing.assert_allclose(got, want, rtol=0, atol=RBF_TOL * np.abs(want).max())
+    got32 = _interpolosis(pts, Z.astype(np.float32), X, Y, 3, d, 0.5)             # values follow the field dtype, solve is double
+    assert got32.dtype == np.float32
+    np.testing.assert_allclose(got32, want, rtol=0, atol=2e-6 * np.abs(want).max())
+    Zn = Z.copy()
+    Zn[5] = np.nan                                                               # poisons exactly the neighbourhoods that hold it
+    wn = orc.interpolosis_rbf(pts, Zn, X, Y, d, 0.5)
+    gn = _interpolosis(pts, Zn, X, Y, 3, d, 0.5)
+    assert np.array_equal(np.isnan(gn), np.isnan(wn)) and np.isnan(wn).any()
+    np.testing.assert_allclose(gn, wn, rtol=0, atol=RBF_TOL * np.abs(want).max(), equal_nan=True)
+    # 4 points: scipy uses neighbors = min(5, P) = 4 -> a 7x7 system
+    p4 = np.array([[0.0, 0.0], [1.0, 0.1], [0.2, 1.0], [1.1, 1.2]])
+    z4 = np.array([1.0, 2.0, 3.0, 5.0])
+    X4, Y4 = np.meshgrid(np.linspace(0.1, 1.0, 5), np.linspace(0.1, 1.0, 4))
+    d4, _ = cKDTree(p4).query(np.column_stack((X4.ravel(), Y4.ravel())))
+    d4 = d4.reshape(X4.shape)
+    np.testing.assert_allclose(_interpolosis(p4, z4, X4, Y4, 3, d4, 5.0), orc.interpolosis_rbf(p4, z4, X4, Y4, d4, 5.0),
+                               rtol=0, atol=1e-12)
+    with pytest.raises(ValueError, match="At least 3 data points"):
+        _interpolosis(p4[:2], z4[:2], X4, Y4, 3, d4, 5.0)
+    # collinear neighbourhood: the monomial block is rank deficient -> LAPACK's zero pivot -> LinAlgError in scipy and here
+    pl = np.column_stack((np.arange(6.0), np.zeros(6)))
+    dl, _ = cKDTree(pl).query(np.column_stack((X4.ravel(), Y4.ravel())))
+    with pytest.raises(np.linalg.LinAlgError):
+        orc.interpolosis_rbf(pl, np.arange(6.0), X4, Y4, dl.reshape(X4.shape), 5.0)
+    with pytest.raises(np.linalg.LinAlgError):
+        _interpolosis(pl, np.arange(6.0), X4, Y4, 3, dl.reshape(X4.shape), 5.0)
 
 
 def test_interpolosis_type1_standalone_matches_scipy(ctx):

@@ -119,6 +119,25 @@ def test_interpolator(golden):
     assert bool(g["miss_is_none"])
 
 
+def test_interpolator_type3_rbf(golden):
+    """RBFInterpolator(neighbors=5) restatement against the reference's own type-3 outputs."""
+    g = golden("interpolator_rbf.npz")
+    s = syn.swath_granule(5005)
+    for tag, (dlat, dlon) in {"fine": (0.25, 0.25), "coarse": (2.0, 2.5)}.items():
+        ctm = syn.regional_ctm_grid(-30.0, 50.0, -25.0, 45.0, dlat, dlon)
+        r = orc.interpolator(3, 0.25, s, ctm, 0.75, record_type=cfg.satellite_amf)
+        assert r is not None and bool(r.ctm_upscaled_needed) == bool(g[f"{tag}_t3_need"])
+        for f in ("vcd", "amf", "uncertainty", "latitude_center", "longitude_center"):
+            want = g[f"{tag}_t3_{f}"]
+            got = np.asarray(getattr(r, f))
+            assert np.array_equal(np.isnan(got), np.isnan(want))
+            np.testing.assert_allclose(got, want, rtol=0, atol=1e-12 * np.nanmax(np.abs(want)), equal_nan=True)
+    pts = np.column_stack((s.longitude_center.ravel(), s.latitude_center.ravel()))
+    for only in (False, True):       # the HIP backend skips masked targets: same answer
+        o = orc.interpolosis_rbf(pts, g["single_Z"], g["single_X"], g["single_Y"], g["single_dists"], 0.25, only_unmasked=only)
+        np.testing.assert_allclose(o, g["single_out"], rtol=0, atol=1e-12 * np.nanmax(np.abs(g["single_out"])), equal_nan=True)
+
+
 def test_records_match_reference(golden):
     g = golden("records.npz")
     for nm in ("satellite_amf", "satellite_opt", "satellite_ssmis", "ctm_model"):
