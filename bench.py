@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=DEFAULT, choices=sorted(WORKLOADS))
     ap.add_argument("--refine", type=int, default=None)
+    ap.add_argument("--species", default="NO2", choices=["NO2", "HCHO", "O3"],
+                    help="parameter set of the synthetic month (BASELINE configs[4]: control_omino2/omihcho/omio3.yml shapes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
@@ -62,19 +64,19 @@ def parse():
     return ap.parse_args()
 
 
-def build_case(workload, seed, lat2=None, lon2=None):
+def build_case(workload, seed, lat2=None, lon2=None, species="NO2"):
     from oisatgmi import synthetic as syn, dense
     ny, nx, nobs, L, swaths, refine = WORKLOADS[workload]
-    p = syn.point_obs_case(ny, nx, nobs, seed, swaths=swaths)
+    p = syn.point_obs_case(ny, nx, nobs, seed, swaths=swaths, species=species)
     if lat2 is None:
         lat2, lon2 = p.lat, p.lon
     cell = dense.regular_grid_cell(lat2, lon2, p.obs_lat, p.obs_lon)
     return p, cell, lat2, lon2
 
 
-def make_plan(ctx, workload, seed, lat2=None, lon2=None):
+def make_plan(ctx, workload, seed, lat2=None, lon2=None, species="NO2"):
     from oisatgmi import dense
-    p, cell, lat2, lon2 = build_case(workload, seed, lat2, lon2)
+    p, cell, lat2, lon2 = build_case(workload, seed, lat2, lon2, species)
     plan = dense.DenseAnalysis(lat2, lon2, max_obs=int(p.obs_y.size), dtype=np.float32, ctx=ctx)
     plan.load_background(p.Xa, p.Sa)
     plan.load_obs(p.obs_lat, p.obs_lon, cell, np.where(p.obs_y < 0, 0, p.obs_y), p.obs_var)
@@ -276,7 +278,7 @@ def main():
     if world > 1:
         lat2, lon2 = parallel.broadcast_grid(lat2 if rank == 0 else None, lon2 if rank == 0 else None, (ny, nx), local)
     # ---- this rank's month ------------------------------------------------------------------------
-    plan = make_plan(ctx, args.workload, 4000 + rank, lat2, lon2)
+    plan = make_plan(ctx, args.workload, 4000 + rank, lat2, lon2, args.species)
     m = plan.m
     gather = parallel.FieldGather(plan, world, rank, local) if world > 1 else None
 
@@ -307,7 +309,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": args.workload, "grid": [ny, nx], "obs_per_month": m, "corr_length_km": L,
+            "config": {"workload": args.workload, "species": args.species, "grid": [ny, nx], "obs_per_month": m, "corr_length_km": L,
                        "refine": refine, "months_per_step": world,
                        "parallelism": "one month per GPU; RCCL broadcast of the grid, all-gather of fields"},
             "solve_tflops_end_to_end": world * flops / (elapsed / args.steps) / 1e12,

@@ -23,6 +23,15 @@ import numpy as np
 
 EARTH_RADIUS_KM = 6371.0
 
+# BASELINE config 5: the three control_*.yml shapes.  ctm_error from
+# run/control_omino2.yml:23, control_omihcho.yml, control_omio3.yml; value ranges = the plotting ranges of
+# report.py:124-146 (x1e15 molec/cm2, O3 in DU); OMI O3 observation error = 4 % of the column (reader.py:1035).
+SPECIES = {
+    "NO2": dict(ctm_error=50.0, value_range=(0.2, 10.0), base=1.0, amp=4.0, obs_err=(0.1, 1.0), rel_obs_err=None),
+    "HCHO": dict(ctm_error=50.0, value_range=(0.5, 20.0), base=3.0, amp=8.0, obs_err=(0.5, 4.0), rel_obs_err=None),
+    "O3": dict(ctm_error=10.0, value_range=(200.0, 500.0), base=250.0, amp=150.0, obs_err=None, rel_obs_err=0.04),
+}
+
 
 def global_grid(ny: int, nx: int):
     """Cell-centred global lat/lon mesh, shape (ny, nx), float64 degrees."""
@@ -123,12 +132,16 @@ class PointObsCase:
 
 
 def point_obs_case(ny: int, nx: int, nobs: int, seed: int, ctm_error: float = 50.0,
-                   swaths: bool = False, cloud_frac: float = 0.6) -> PointObsCase:
+                   swaths: bool = False, cloud_frac: float = 0.6, species: str = "NO2") -> PointObsCase:
     """Random (lat, lon) observations.  ``swaths=True`` gives the OMI-NO2-style layout of
-    BASELINE config 3: 14-15 stripes ~2600 km wide with ``cloud_frac`` of the pixels dropped."""
+    BASELINE config 3: 14-15 stripes ~2600 km wide with ``cloud_frac`` of the pixels dropped.
+    ``species`` picks one of the ``SPECIES`` parameter sets (config 5); the default is the NO2 case."""
+    sp = SPECIES[species]
+    if species != "NO2":
+        ctm_error = sp["ctm_error"]
     rng = np.random.default_rng(seed)
     lat2, lon2 = global_grid(ny, nx)
-    xa = background_field(rng, lat2, lon2)
+    xa = background_field(rng, lat2, lon2, lo=sp["value_range"][0], hi=sp["value_range"][1], base=sp["base"], amp=sp["amp"])
     g = _smooth_unit_field(rng, lat2, lon2)
     truth = xa * (1.0 + 0.3 * g)
     if not swaths:
@@ -156,7 +169,10 @@ def point_obs_case(ny: int, nx: int, nobs: int, seed: int, ctm_error: float = 50
     # truth at the observation = truth of the containing cell
     iy = np.clip(np.floor((olat + 90.0) / (180.0 / ny)).astype(np.int64), 0, ny - 1)
     ix = np.clip(np.floor((olon + 180.0) / (360.0 / nx)).astype(np.int64), 0, nx - 1)
-    sig = rng.uniform(0.1, 1.0, size=nobs)
+    if sp["rel_obs_err"] is None:
+        sig = rng.uniform(sp["obs_err"][0], sp["obs_err"][1], size=nobs)
+    else:
+        sig = sp["rel_obs_err"] * np.abs(truth[iy, ix])
     y = truth[iy, ix] + rng.normal(size=nobs) * sig
     Sa = (xa * ctm_error / 100.0) ** 2
     return PointObsCase(lat2, lon2, xa, Sa, olat, olon, y, sig ** 2, truth)

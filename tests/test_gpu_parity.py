@@ -602,6 +602,26 @@ def test_dense_analysis_against_oracle(ctx, ny, nx, m, L):
         assert np.abs(info["z"] - ref["z"]).max() <= ztol * np.abs(ref["z"]).max()
 
 
+@pytest.mark.parametrize("species", ["NO2", "HCHO", "O3"])
+def test_dense_analysis_per_species(ctx, species):
+    """BASELINE config 5 shapes (control_omino2 / control_omihcho / control_omio3.yml): the three parameter sets
+    differ in ctm_error (50/50/10 %), value range (0-10, 0-20 x1e15 molec/cm2, 200-500 DU) and observation error
+    (absolute vs 4 % of the column, reader.py:1035), i.e. in the conditioning of H B H^T + R."""
+    L = 400.0
+    p = syn.point_obs_case(90, 180, 2000, 5000 + len(species), swaths=True, species=species)
+    cell = dense.regular_grid_cell(p.lat, p.lon, p.obs_lat, p.obs_lon)
+    ref = orc.dense_oi(p.lat, p.lon, p.Xa, p.Sa, p.obs_lat, p.obs_lon, cell, np.where(p.obs_y < 0, 0, p.obs_y), p.obs_var, L)
+    xb, inc, info = dense.OI_dense(p.Xa, None, p.Sa, None, p.lat, p.lon, L, refine=2, dtype=np.float32,
+                                   obs=dict(lat=p.obs_lat, lon=p.obs_lon, y=p.obs_y, var=p.obs_var))
+    scale = np.abs(ref["xa"]).max()
+    assert np.abs(xb.ravel() - ref["xa"]).max() <= 1e-5 * scale, np.abs(xb.ravel() - ref["xa"]).max() / scale
+    assert np.abs(inc.ravel() - ref["inc"]).max() <= 1e-5 * scale
+    assert info["residuals"][-1] < 1e-9
+    # the analysis moves towards the observations: smaller misfit at the observed cells than the background
+    y = np.where(p.obs_y < 0, 0, p.obs_y)
+    assert np.abs(xb.ravel()[cell] - y).mean() < np.abs(p.Xa.ravel()[cell] - y).mean()
+
+
 def test_dense_pieces_through_the_c_abi(ctx):
     """cov_build / potrf / potrs individually, ragged size (m not a multiple of the 128 block)."""
     lib = ctx.lib
