@@ -103,7 +103,13 @@ __global__ __launch_bounds__(256) void cov_residual_kernel(const double* __restr
 
 // ---- inc_i = sig_i * sum_a C(i,a) w_a, w = osig.*z ; xa = xb + inc --------------------------------------------
 // Thread = CELLS grid cells, block = 256 threads; observations stream through LDS in chunks and
-// are read as wave-uniform (broadcast) float4.  fp32 inside a chunk, double across chunks.
+// are read as wave-uniform (broadcast) 16-byte words.  |p-q|^2 is formed in double: with float
+// coordinates the rounding of the inputs alone (3e-8 each) moves the exponent by g*2|p-q|*3e-8 ~ 1e-6
+// at the ranges that matter, and the increment -- a sum of ~1e3 such terms of both signs -- was off by
+// 1.3e-5 of the field scale at 720x1440 / 1e5 obs.  v_fma_f64 issues at the unpacked fp32 rate on
+// CDNA4, so this costs a few extra issue slots per pair, not a factor.  exp2 stays fp32 (v_exp_f32); the
+// product with sig*z and the running sum are double, because the terms cancel: sum|term| reaches several
+// hundred times the field scale at swath densities, so fp32 partial sums alone cost ~1e-5.
 template <typename T, int CELLS>
 __global__ __launch_bounds__(256) void apply_increment_kernel(const double* __restrict__ gxyz, const double* __restrict__ gsig,
                                                                int64_t n, const double* __restrict__ oxyz,
@@ -111,42 +117,40 @@ __global__ __launch_bounds__(256) void apply_increment_kernel(const double* __re
                                                                int64_t m, float g2,
                                                                const T* __restrict__ xb, T* __restrict__ xa, T* __restrict__ inc) {
     constexpr int CH = 512;
-    __shared__ float4 so[CH];
+    __shared__ double2 sxy[CH], szw[CH];                    // (x, y) and (z, sig*z_solve)
     const int t = threadIdx.x;
-    float px[CELLS], py[CELLS], pz[CELLS];
+    double px[CELLS], py[CELLS], pz[CELLS];
     double acc[CELLS];
     int64_t cell[CELLS];
 #pragma unroll
     for (int q = 0; q < CELLS; ++q) {
         cell[q] = ((int64_t)blockIdx.x * CELLS + q) * 256 + t;
         const bool live = cell[q] < n;
-        px[q] = live ? (float)gxyz[cell[q]] : 0.f;
-        py[q] = live ? (float)gxyz[n + cell[q]] : 0.f;
-        pz[q] = live ? (float)gxyz[2 * n + cell[q]] : 0.f;
+        px[q] = live ? gxyz[cell[q]] : 0.0;
+        py[q] = live ? gxyz[n + cell[q]] : 0.0;
+        pz[q] = live ? gxyz[2 * n + cell[q]] : 0.0;
         acc[q] = 0.0;
     }
     for (int64_t c0 = 0; c0 < m; c0 += CH) {
         __syncthreads();
         for (int j = t; j < CH; j += 256) {
             const int64_t c = c0 + j;
-            so[j] = c < m ? make_float4((float)oxyz[c], (float)oxyz[m + c], (float)oxyz[2 * m + c], (float)(osig[c] * z[c]))
-                          : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool live = c < m;
+            sxy[j] = live ? make_double2(oxyz[c], oxyz[m + c]) : make_double2(0.0, 0.0);
+            szw[j] = live ? make_double2(oxyz[2 * m + c], osig[c] * z[c]) : make_double2(0.0, 0.0);
         }
         __syncthreads();
-        float part[CELLS];
-#pragma unroll
-        for (int q = 0; q < CELLS; ++q) part[q] = 0.f;
 #pragma unroll 4
         for (int j = 0; j < CH; ++j) {
-            const float4 o = so[j];
+            const double2 oxy = sxy[j];
+            const double2 ozw = szw[j];
 #pragma unroll
             for (int q = 0; q < CELLS; ++q) {
-                const float dx = px[q] - o.x, dy = py[q] - o.y, dz = pz[q] - o.z;
-                part[q] += __builtin_amdgcn_exp2f(-g2 * (dx * dx + dy * dy + dz * dz)) * o.w;
+                const double dx = px[q] - oxy.x, dy = py[q] - oxy.y, dz = pz[q] - ozw.x;
+                const float d2 = (float)(dx * dx + dy * dy + dz * dz);
+                acc[q] += (double)__builtin_amdgcn_exp2f(-g2 * d2) * ozw.y;
             }
         }
-#pragma unroll
-        for (int q = 0; q < CELLS; ++q) acc[q] += (double)part[q];
     }
 #pragma unroll
     for (int q = 0; q < CELLS; ++q) {
