@@ -303,7 +303,15 @@ def OI_dense(Xa, Y, Sa, So, lat, lon, L_km, scale=1.0, refine=2, obs=None, dtype
         ovar = np.ravel(obs["var"])
         cell = regular_grid_cell(lat, lon, olat, olon)
     dt = np.dtype(dtype) if dtype is not None else _hip.compute_dtype(Xa)
-    plan = DenseAnalysis(lat, lon, max_obs=max(int(cell.size), 1), dtype=dt)
+    if cell.size == 0:                 # a month without a single usable observation: nothing to spread, x_a = x_b
+        _hip.context()                 # (still no CPU path: fail here if the library or the GPU is missing)
+        extra = {}
+        if want_error:
+            extra = {"ak": np.full(np.shape(Xa), np.nan), "err": np.sqrt(np.asarray(Sa, dtype=np.float64) * scale),
+                     "ak_obs": np.empty(0)}
+        return (np.array(Xa, dtype=dt), np.zeros(np.shape(Xa), dtype=dt),
+                {"nobs": 0, "residuals": [], "cells": cell, "z": np.empty(0), **extra})
+    plan = DenseAnalysis(lat, lon, max_obs=int(cell.size), dtype=dt)
     xa_f = np.where(np.isfinite(Xa), Xa, 0.0)
     sa_f = np.where(np.isfinite(Sa), Sa, 0.0)
     plan.load_background(xa_f, sa_f, scale=scale)

@@ -602,6 +602,26 @@ def test_dense_analysis_against_oracle(ctx, ny, nx, m, L):
         assert np.abs(info["z"] - ref["z"]).max() <= ztol * np.abs(ref["z"]).max()
 
 
+def test_dense_edge_sizes(ctx):
+    """Observation counts around the 128-row blocking of the factorization, down to one and to none."""
+    for m in (0, 1, 2, 5, 127, 128, 129, 257):
+        p = syn.point_obs_case(36, 72, max(m, 1), 77 + m)
+        obs = dict(lat=p.obs_lat[:m], lon=p.obs_lon[:m], y=p.obs_y[:m], var=p.obs_var[:m])
+        xb, inc, info = dense.OI_dense(p.Xa, None, p.Sa, None, p.lat, p.lon, 600.0, refine=2, dtype=np.float32, obs=obs,
+                                       want_error=True)
+        assert info["nobs"] == m and xb.dtype == np.float32 and xb.shape == p.Xa.shape
+        if m == 0:                     # nothing observed: the analysis is the background
+            np.testing.assert_array_equal(xb, p.Xa.astype(np.float32))
+            assert not inc.any() and np.isnan(info["ak"]).all()
+            np.testing.assert_allclose(info["err"], np.sqrt(p.Sa))
+            continue
+        cell = dense.regular_grid_cell(p.lat, p.lon, obs["lat"], obs["lon"])
+        ref = orc.dense_oi(p.lat, p.lon, p.Xa, p.Sa, obs["lat"], obs["lon"], cell, np.where(obs["y"] < 0, 0, obs["y"]),
+                           obs["var"], 600.0)
+        assert np.abs(xb.ravel() - ref["xa"]).max() <= 1e-6 * np.abs(ref["xa"]).max(), m
+        assert info["residuals"][-1] < 1e-12
+
+
 @pytest.mark.parametrize("species", ["NO2", "HCHO", "O3"])
 def test_dense_analysis_per_species(ctx, species):
     """BASELINE config 5 shapes (control_omino2 / control_omihcho / control_omio3.yml): the three parameter sets
