@@ -211,7 +211,7 @@ class TiledAnalysis:
     tile's observations + halo), run back to back on the stream with ONE shared factor workspace.
     Tiles are independent work units -- ``parallel.shard_units`` spreads (month x tile) over GPUs."""
 
-    def __init__(self, grid_lat, grid_lon, tile_deg=30.0, halo_km=900.0, dtype=np.float32, ctx=None, streams=6):
+    def __init__(self, grid_lat, grid_lon, tile_deg=30.0, halo_km=900.0, dtype=np.float32, ctx=None, streams=12):
         self.ctx = ctx or _hip.context()
         # extra handles on the same device, each with its own stream, workspaces and factor: tiles are
         # independent, and a 4,000-8,000-observation solve leaves most of the 256 CUs idle on its own
@@ -231,9 +231,15 @@ class TiledAnalysis:
         s_all = sig.ravel()[cell]
         ovar = np.ravel(obs_var)
         self.tiles = [t for t in tile_partition(self.lat2, self.lon2, olat, olon, self.tile_deg, self.halo_km)]
-        # largest tiles first, dealt round-robin to the lanes (each lane: one stream, one shared factor workspace)
+        # largest tiles first, each to the lane with the least factorization work so far (cost ~ m^3);
+        # a lane is one stream with one shared factor workspace
         order = sorted(range(len(self.tiles)), key=lambda i: -self.tiles[i]["obs"].size)
-        lane_of = {ti: k % len(self.lanes) for k, ti in enumerate(order)}
+        load = [0.0] * len(self.lanes)
+        lane_of = {}
+        for ti in order:
+            li = min(range(len(load)), key=load.__getitem__)
+            lane_of[ti] = li
+            load[li] += float(self.tiles[ti]["obs"].size) ** 3
         self.S = []
         for li, lane in enumerate(self.lanes):
             mmax = max((self.tiles[ti]["obs"].size for ti in order if lane_of[ti] == li), default=0)
