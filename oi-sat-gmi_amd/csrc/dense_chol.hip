@@ -187,36 +187,40 @@ __device__ __forceinline__ float rdlane(float v, int l) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
 
+// Factor and invert in ONE sweep: column k of L is final after pivot step k, and that is exactly when the forward
+// substitution for X = L^-1 (lane = column r of X) needs it, so each broadcast L[c][k] = readlane(d[k], c) feeds both
+// the trailing update of the factor and the running sums of the inverse.  Half the serial broadcasts of doing the
+// two one after the other.
 __device__ __forceinline__ void diag16_factor_invert(float* a, int j0, float* dinvJ, int* info, int col0, int lane) {
     const int r = lane & 15;
-    float d[16], rinv[16], x[16];
+    float d[16], x[16];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) d[c] = a[(j0 + r) * LDA + j0 + c];
+    for (int c = 0; c < 16; ++c) {
+        d[c] = a[(j0 + r) * LDA + j0 + c];
+        x[c] = (c == r) ? 1.f : 0.f;                       // running delta_{c,r} - sum_{k<c} L[c][k] X[k][r]
+    }
+    int bad = 0;                                           // first non-positive / NaN pivot (wave-uniform), reported once below
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         float piv = rdlane(d[k], k);
-        if (!(piv > 0.f)) {                               // non-positive or NaN pivot (wave-uniform)
-            if (lane == 0) atomicCAS(info, 0, col0 + k + 1);
-            piv = 1.f;
-        }
+        const bool neg = !(piv > 0.f);
+        bad = (neg && bad == 0) ? k + 1 : bad;
+        piv = neg ? 1.f : piv;
         float ri = __builtin_amdgcn_rsqf(piv);
         ri = ri * (1.5f - 0.5f * piv * ri * ri);          // one Newton step: ~0.5 ulp
-        rinv[k] = ri;
         d[k] = (r == k) ? piv * ri : d[k] * ri;
+        x[k] = (k >= r) ? x[k] * ri : 0.f;
 #pragma unroll
-        for (int c = k + 1; c < 16; ++c) d[c] -= d[k] * rdlane(d[k], c);
+        for (int c = k + 1; c < 16; ++c) {
+            const float l = rdlane(d[k], c);              // L[c][k]
+            d[c] -= d[k] * l;
+            x[c] -= l * x[k];
+        }
     }
+    if (bad && lane == 0) atomicCAS(info, 0, col0 + bad);
 #pragma unroll
     for (int c = 0; c < 16; ++c)
         if (lane < 16) a[(j0 + r) * LDA + j0 + c] = (c <= r) ? d[c] : 0.f;
-    // inverse, lane = column r of X = L_D^-1
-#pragma unroll
-    for (int rr = 0; rr < 16; ++rr) {
-        float v = (rr == r) ? 1.f : 0.f;
-#pragma unroll
-        for (int k = 0; k < rr; ++k) v -= rdlane(d[k], rr) * x[k];
-        x[rr] = (rr >= r) ? v * rinv[rr] : 0.f;
-    }
 #pragma unroll
     for (int rr = 0; rr < 16; ++rr)
         if (lane < 16) dinvJ[rr * DINV_LD + r] = x[rr];
@@ -231,18 +235,18 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(float* __restrict__ S, 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int lr = lane & 15, lg = lane >> 4;
     float* Sb = S + k0 * ld + k0;
-    {   // 16 independent 16-byte loads per thread, issued together (row = (tid>>5)+8p, 4 columns at (tid&31)*4)
+    {   // 16 independent 16-byte loads per thread, issued together (row = (tid>>5)+8p, 4 columns at (tid&31)*4).
+        // Row stride 130 floats keeps (r, c) with c % 4 == 0 8-byte aligned: two ds_write_b64 per quad.
+        // (t needs no clearing: every element of it that is read later has been written by then.)
         float4 v[16];
 #pragma unroll
         for (int p = 0; p < 16; ++p) v[p] = *reinterpret_cast<const float4*>(Sb + (int64_t)((tid >> 5) + 8 * p) * ld + (tid & 31) * 4);
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
             const int r = (tid >> 5) + 8 * p, c = (tid & 31) * 4;
-            float* q = a + r * LDA + c;
-            float* z = t + r * LDA + c;
-            q[0] = (c + 0 <= r) ? v[p].x : 0.f; q[1] = (c + 1 <= r) ? v[p].y : 0.f;
-            q[2] = (c + 2 <= r) ? v[p].z : 0.f; q[3] = (c + 3 <= r) ? v[p].w : 0.f;
-            z[0] = 0.f; z[1] = 0.f; z[2] = 0.f; z[3] = 0.f;
+            float2* q = reinterpret_cast<float2*>(a + r * LDA + c);
+            q[0] = make_float2((c + 0 <= r) ? v[p].x : 0.f, (c + 1 <= r) ? v[p].y : 0.f);
+            q[1] = make_float2((c + 2 <= r) ? v[p].z : 0.f, (c + 3 <= r) ? v[p].w : 0.f);
         }
     }
     __syncthreads();
@@ -333,19 +337,30 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(float* __restrict__ S, 
     }
     float* Tg = tinv + (int64_t)block_index * NB * NB;
 #pragma unroll
-    for (int p = 0; p < 16; ++p) {
-        const int r = (tid >> 5) + 8 * p, c = (tid & 31) * 4;
-        const float* q = a + r * LDA + c;
-        const float* z = t + r * LDA + c;
-        float* g = Sb + (int64_t)r * ld + c;
-        if (c + 3 <= r) *reinterpret_cast<float4*>(g) = make_float4(q[0], q[1], q[2], q[3]);
-        else {
-            if (c + 0 <= r) g[0] = q[0];
-            if (c + 1 <= r) g[1] = q[1];
-            if (c + 2 <= r) g[2] = q[2];
+    for (int hp = 0; hp < 2; ++hp) {       // LDS reads of 8 rows first (ds_read_b64), then their stores
+        float2 ql[8][2], zl[8][2];
+#pragma unroll
+        for (int pp = 0; pp < 8; ++pp) {
+            const int r = (tid >> 5) + 8 * (hp * 8 + pp), c = (tid & 31) * 4;
+            const float2* q = reinterpret_cast<const float2*>(a + r * LDA + c);
+            const float2* z = reinterpret_cast<const float2*>(t + r * LDA + c);
+            ql[pp][0] = q[0]; ql[pp][1] = q[1];
+            zl[pp][0] = z[0]; zl[pp][1] = z[1];
         }
-        *reinterpret_cast<float4*>(Tg + r * NB + c) = make_float4(c + 0 <= r ? z[0] : 0.f, c + 1 <= r ? z[1] : 0.f,
-                                                                   c + 2 <= r ? z[2] : 0.f, c + 3 <= r ? z[3] : 0.f);
+#pragma unroll
+        for (int pp = 0; pp < 8; ++pp) {
+            const int r = (tid >> 5) + 8 * (hp * 8 + pp), c = (tid & 31) * 4;
+            float* g = Sb + (int64_t)r * ld + c;
+            if (c + 3 <= r) *reinterpret_cast<float4*>(g) = make_float4(ql[pp][0].x, ql[pp][0].y, ql[pp][1].x, ql[pp][1].y);
+            else {
+                if (c + 0 <= r) g[0] = ql[pp][0].x;
+                if (c + 1 <= r) g[1] = ql[pp][0].y;
+                if (c + 2 <= r) g[2] = ql[pp][1].x;
+            }
+            // T above the diagonal was never written in LDS: select, do not multiply
+            *reinterpret_cast<float4*>(Tg + r * NB + c) = make_float4(c + 0 <= r ? zl[pp][0].x : 0.f, c + 1 <= r ? zl[pp][0].y : 0.f,
+                                                                       c + 2 <= r ? zl[pp][1].x : 0.f, c + 3 <= r ? zl[pp][1].y : 0.f);
+        }
     }
 }
 
