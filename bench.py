@@ -221,8 +221,8 @@ def cpu_baseline(workload):
     from oracle import oi_oracle as orc
     ny, nx, nobs, L, swaths, _ = WORKLOADS[workload]
     p, cell, _, _ = build_case(workload, 424242)
-    m_s = min(int(p.obs_y.size), 5000)
-    ncell_s = min(p.Xa.size, 32768)
+    m_s = min(int(p.obs_y.size), 8000)
+    ncell_s = min(p.Xa.size, 65536)
     obs_cells = np.unique(cell[:m_s])
     rest = np.setdiff1d(np.random.default_rng(1).choice(p.Xa.size, ncell_s, replace=False), obs_cells)
     sel = np.concatenate([obs_cells, rest])[:max(ncell_s, obs_cells.size)]
