@@ -111,7 +111,8 @@ int oisat_oi_variances(oisat_ctx* h, int dtype, const void* Xa, const void* sat_
 int oisat_scaling_factor(oisat_ctx* h, int dtype, const void* posterior, const void* prior, int64_t n, void* out);
 
 /* ---- AMF recalculation (upstream of the averaging): amf_recal.py ---------------------------------------- */
-/* Model partial column deltap*profile/g/Mair*N_A*1e-4*1e-15*100*1e-9, left to right in `dtype` (:51-56). */
+/* Model partial column deltap*profile/g/Mair*N_A*1e-4*1e-15*100*1e-9, left to right in `dtype` (:51-56).
+ * profile == NULL: the air column deltap/g/Mair*N_A*1e-4*1e-15*100 (ak_conv_mopitt.py:66). */
 int oisat_partial_column(oisat_ctx* h, int dtype, const void* deltap, const void* profile, int64_t n, void* out);
 
 /* Per-pixel vertical interpolation and AMF (the Python double loop :93-119 plus the record update :176-182):
@@ -129,6 +130,26 @@ int oisat_amf_recal(oisat_ctx* h, const double* sat_pmid, const double* sat_sw, 
  * p < tropopause dropped when tropopause != NULL), NaN where vcd is NaN; cube and output in `dtype`. */
 int oisat_column_sum(oisat_ctx* h, int dtype, const void* ctm_pmid, const void* ctm_partial, int nzc,
                      const double* tropopause, const double* vcd, int64_t n, void* ctm_vcd);
+
+/* ---- averaging-kernel convolution: ak_conv_mopitt.py / ak_conv_gosat.py (driver.py:46-51 conv_ak) ------------
+ * The satellite_opt counterpart of oisat_amf_recal: per pixel the model column (cubes of dtype ctm_dtype,
+ * level-major [nzc][n]) is interpolated in log-pressure onto the satellite levels (double, [nzs][n]) with
+ * scipy interp1d's arithmetic, then the retrieval's averaging kernels are applied.
+ * MOPITT (ak_conv_mopitt.py:118-146): fill NaN outside the model's pressure range; averaging_kernels is
+ *   [nzs+1][n] (row 0 = surface); model_vcd = aprior_column + nansum(AK[1:]*(log10 x - log10 apriori_profile))
+ *   + AK[0]*(log10 x_model[0] - log10 apriori_surface); model_xcol = 1e6*model_vcd/nansum(air partial column);
+ *   pixels with NaN vcd are skipped (both NaN), +/-inf vcd -> model_vcd NaN.
+ * GOSAT (ak_conv_gosat.py:118-143): linear extrapolation; model_xcol = nansum over levels of
+ *   pressure_weight*(apriori + AK*(x - apriori)) with non-positive terms dropped; NaN/inf x_col -> NaN. */
+int oisat_ak_conv_mopitt(oisat_ctx* h, int ctm_dtype, const void* ctm_pmid, const void* ctm_profile,
+                         const void* ctm_air_partial, int nzc, const double* sat_pmid,
+                         const double* averaging_kernels, const double* apriori_profile, int nzs,
+                         const double* aprior_column, const double* apriori_surface, const double* vcd,
+                         int64_t n, double* model_vcd, double* model_xcol);
+int oisat_ak_conv_gosat(oisat_ctx* h, int ctm_dtype, const void* ctm_pmid, const void* ctm_profile, int nzc,
+                        const double* sat_pmid, const double* averaging_kernels,
+                        const double* apriori_profile, const double* pressure_weight, int nzs,
+                        const double* x_col, int64_t n, double* model_xcol);
 
 /* ---- regridding: interpolator.py:10-97 --------------------------------------------------------- */
 /* signal.convolve2d(Z, ones(ky,kx)/(kx*ky)^(1|2), boundary='symm', mode='same'),

@@ -1,13 +1,13 @@
 """The ``oisatgmi`` facade -- hot-path methods on the MI355X.
 
-Drop-in for the three methods of ``oisatgmi/driver.py`` that lie on the optimal-interpolation
-path: ``average`` (:53-63), ``bias_correct`` (:65-106) and ``oi`` (:108-114), with the same
-attribute names set on ``self``.  The I/O methods of the reference's class (``read_data``,
-``cal_pwv``, ``conv_ak``, ``reporting``, ``savedaily``) are file
-formats, plotting and sensor-specific operators outside this path; ``write_to_nc`` (the output stage,
-SURVEY.md section 8(f) row 4) is kept: same variables, with the scaling-factor rule evaluated on the device:
-they raise ``NotImplementedError`` here -- see INTEGRATION.md for binding the HIP path into the
-reference's own class instead.
+Drop-in for the methods of ``oisatgmi/driver.py`` that lie on the optimal-interpolation path:
+``average`` (:53-63), ``bias_correct`` (:65-106) and ``oi`` (:108-114), the two vertical operators
+feeding them -- ``recal_amf`` (:35-38) and ``conv_ak`` (:46-51) -- and the output stage ``write_to_nc``
+(:156-227; same variables, the scaling-factor rule evaluated on the device), with the same attribute
+names set on ``self``.  The remaining methods of the reference's class (``read_data``, ``cal_pwv``,
+``reporting``, ``savedaily``) are file formats, plotting and a sensor-specific operator outside this
+path: they raise ``NotImplementedError`` here -- see INTEGRATION.md
+for binding the HIP path into the reference's own class instead.
 """
 from __future__ import annotations
 
@@ -152,8 +152,14 @@ class oisatgmi(object):
     def cal_pwv(self, *a, **k):
         self._out_of_scope("cal_pwv")
 
-    def conv_ak(self, *a, **k):
-        self._out_of_scope("conv_ak")
+    def conv_ak(self, sensor: str):
+        """driver.py:46-51 of the reference."""
+        if sensor == 'MOPITT':
+            from .ak_conv_mopitt import ak_conv_mopitt
+            self.reader_obj.sat_data = ak_conv_mopitt(self.reader_obj.ctm_data, self.reader_obj.sat_data)
+        if sensor == 'GOSAT':
+            from .ak_conv_gosat import ak_conv_gosat
+            self.reader_obj.sat_data = ak_conv_gosat(self.reader_obj.ctm_data, self.reader_obj.sat_data)
 
     def reporting(self, *a, **k):
         self._out_of_scope("reporting")

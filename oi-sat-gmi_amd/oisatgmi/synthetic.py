@@ -302,3 +302,65 @@ def amf_granules(ctm, nzs: int, k: int, seed: int, with_sw: bool = True, with_tr
         out.append(satellite_amf(vcd, amf, when, trop, lat2, lon2, [], [], unc, [], p, sw, False, [], [], [], []))
     out.insert(1, None)
     return out
+
+
+def ctm_monthly(ny: int, nx: int, nz: int, nmonths: int, seed: int, ctmtype: str = "ECCOH", dtype=np.float32,
+                lat0=-30.0, lat1=30.0, lon0=-40.0, lon1=40.0, year=2019, month0=5):
+    """Model records as the averaging-kernel convolution consumes them (ak_conv_mopitt.py:60-77): ``ECCOH`` / ``FREE``
+    records hold one monthly mean, cubes (1, nz, ny, nx); ``GMI`` records hold 8 time slots that are nan-averaged."""
+    from .config import ctm_model
+    rng = np.random.default_rng(seed)
+    lat = np.linspace(lat0, lat1, ny)
+    lon = np.linspace(lon0, lon1, nx)
+    lon2, lat2 = np.meshgrid(lon, lat)
+    edges = np.linspace(1000.0, 60.0, nz + 1)
+    pm = 0.5 * (edges[:-1] + edges[1:])
+    dp = (edges[:-1] - edges[1:])
+    nt = 8 if ctmtype == "GMI" else 1
+    out = []
+    for mth in range(nmonths):
+        times = [_dt.datetime(year, month0 + mth, 1, 3 * h if nt > 1 else 0, 0) for h in range(nt)]
+        wob = 1.0 + 0.01 * rng.normal(size=(nt, 1, ny, nx))
+        pmid = (pm[None, :, None, None] * wob).astype(dtype)
+        delp = (dp[None, :, None, None] * wob).astype(dtype)
+        prof = (rng.lognormal(mean=4.0, sigma=0.3, size=(nt, nz, ny, nx)) * np.exp(-np.arange(nz) / 9.0)[None, :, None, None]).astype(dtype)
+        if nt > 1:
+            prof[3, :, 1, 2] = np.nan                        # a missing time slot: nanmean skips it
+        out.append(ctm_model(lat2, lon2, times, prof, pmid, np.zeros_like(pmid), delp, ctmtype, False))
+    return out
+
+
+def opt_granules(ctm, nzs: int, k: int, seed: int, sensor: str = "MOPITT"):
+    """``k`` gridded optimal-estimation granules (``satellite_opt``) on the model grid for ``conv_ak``:
+    MOPITT carries nzs profile levels + 1 surface averaging-kernel row and log10 a-priori terms
+    (ak_conv_mopitt.py:118-138); GOSAT carries nzs levels, pressure weights and XCH4 (ak_conv_gosat.py:118-135)."""
+    from .config import satellite_opt
+    rng = np.random.default_rng(seed)
+    lat2, lon2 = ctm[0].latitude, ctm[0].longitude
+    ny, nx = lat2.shape
+    out = []
+    for g in range(k):
+        when = _dt.datetime(2019, 5 + g % 2, 3 + g, 10, 30)
+        # satellite levels overshoot the model's pressure range at both ends: NaN (MOPITT) / extrapolation (GOSAT) there
+        p = np.linspace(1030.0, 40.0, nzs)[:, None, None] * (1 + 0.004 * rng.normal(size=(nzs, ny, nx)))
+        if g % 2:
+            p = p[::-1].copy()
+        ap = rng.lognormal(mean=4.0, sigma=0.2, size=(nzs, ny, nx))
+        vcd = rng.uniform(1.0, 3.0, size=(ny, nx))
+        xcol = rng.uniform(1700.0, 1900.0, size=(ny, nx))
+        for a in (vcd, xcol):
+            a[rng.uniform(size=a.shape) < 0.15] = np.nan
+            a[2, 3] = np.inf
+        unc = rng.uniform(0.05, 0.3, size=(ny, nx))
+        if sensor == "MOPITT":
+            ak = rng.normal(scale=0.3, size=(nzs + 1, ny, nx))
+            pw = np.empty((1))
+        else:
+            ak = rng.uniform(0.2, 1.4, size=(nzs, ny, nx))
+            pw = rng.dirichlet(np.ones(nzs), size=(ny, nx)).transpose(2, 0, 1).copy()
+            pw[0, 1, 1] = -pw[0, 1, 1]                      # a non-positive term is dropped (ak_conv_gosat.py:133)
+        out.append(satellite_opt(vcd, when, [], np.empty((1)), lat2, lon2, [], [], unc, [], p, ak, False, [], [], [],
+                                 rng.uniform(17.5, 18.5, size=(ny, nx)), ap, rng.uniform(950.0, 1020.0, size=(ny, nx)),
+                                 rng.lognormal(mean=4.2, sigma=0.2, size=(ny, nx)), xcol, pw, sensor))
+    out.insert(1, None)
+    return out

@@ -12,6 +12,8 @@ Pinning status ("Oracle"):
   ``_upscaler``, ``_interpolosis`` types 1-4 and ``interpolator`` (2-D field path) are PINNED:
   ``tests/golden/*.npz`` hold outputs of the reference's own functions, produced in the build
   container by ``tests/golden/make_golden.py`` importing the reference modules.
+* ``amf_recal`` and ``ak_conv`` (MOPITT / GOSAT averaging-kernel convolution) are PINNED the same way
+  (``amf_recal.npz``, ``ak_conv.npz``).
 * The knee index chosen from that curve comes from the third-party package ``kneed==0.8.3``
   (requirements.txt:9; call site optimal_interpolation.py:37-39), which is neither vendored in the
   reference nor installed here: ``kneedle_knee`` restates its published algorithm and is
@@ -495,6 +497,87 @@ def amf_recal(ctm_data, sat_data):
         mv[np.isnan(L2.vcd)] = np.nan
         mv[np.isinf(L2.vcd)] = np.nan
         L2.ctm_vcd, L2.ctm_time_at_sat = mv, tc[ci]
+    return sat_data
+
+
+# --------------------------------------------------------------------------------------------
+# ak_conv_mopitt.py / ak_conv_gosat.py  (the satellite_opt counterpart of amf_recal, driver.py:46-51)
+# --------------------------------------------------------------------------------------------
+def air_partial_column(deltap):
+    """ak_conv_mopitt.py:66."""
+    return deltap / 9.80665 / 28.97e-3 * 6.02214076e23 * 1e-4 * 1e-15 * 100.0
+
+
+def mopitt_pixel(ctm_p, ctm_prof, ctm_air, sat_p, ak, ap_prof, ap_col, ap_surf):
+    """One pixel of ak_conv_mopitt.py:120-138 -> (model_VCD, model_xcol)."""
+    f = _interp1d(np.log(ctm_p), ctm_prof, fill_value=np.nan, bounds_error=False)
+    with np.errstate(all="ignore"):
+        xi = f(np.log(sat_p))
+        prof_part = ap_col + np.nansum(ak[1:] * (np.log10(xi) - np.log10(ap_prof)))
+        surf_part = ak[0] * (np.log10(ctm_prof[0]) - np.log10(ap_surf))
+        v = prof_part + surf_part
+        return v, 1e6 * v / np.nansum(ctm_air)
+
+
+def gosat_pixel(ctm_p, ctm_prof, sat_p, ak, ap_prof, pw):
+    """One pixel of ak_conv_gosat.py:124-135 -> model_xcol."""
+    f = _interp1d(np.log(ctm_p), ctm_prof, fill_value="extrapolate")
+    with np.errstate(all="ignore"):
+        xi = f(np.log(sat_p))
+        t = (ap_prof + (xi - ap_prof) * ak) * pw
+        t[t <= 0] = np.nan
+        return np.nansum(t)
+
+
+def ak_conv(ctm_data, sat_data, sensor):
+    """``ak_conv_mopitt`` (ak_conv_mopitt.py:8-149) / ``ak_conv_gosat`` (ak_conv_gosat.py:8-146).  Mutates and
+    returns ``sat_data`` like the reference."""
+    tc = np.array([_flat_time(t) for rec in ctm_data for t in rec.time])
+    for L2 in sat_data:
+        if L2 is None:
+            continue
+        ts = L2.time.year * 10000 + L2.time.month * 100 + L2.time.day
+        ci = int(np.argmin(np.abs(ts - tc))) if not ctm_data[0].averaged else 0
+        rec = ctm_data[ci]                                  # (the reference indexes records with the time-slot index)
+        if rec.ctmtype in ("ECCOH", "FREE"):
+            pmid, prof, delp = rec.pressure_mid.squeeze(), rec.gas_profile.squeeze(), rec.delta_p.squeeze()
+        elif rec.ctmtype == "GMI":
+            with np.errstate(all="ignore"):
+                pmid = np.nanmean(rec.pressure_mid, axis=0).squeeze()
+                prof = np.nanmean(rec.gas_profile, axis=0).squeeze()
+                delp = np.nanmean(rec.delta_p, axis=0).squeeze()
+        else:
+            raise NameError("ctm_mid_pressure is not defined for ctmtype " + str(rec.ctmtype))
+        air = air_partial_column(delp)
+        if L2.ctm_upscaled_needed:
+            coord = {"Longitude": L2.longitude_center, "Latitude": L2.latitude_center}
+            thr = np.sqrt(np.abs(coord["Longitude"][0, 0] - coord["Longitude"][0, 1]) ** 2 +
+                          np.abs(coord["Latitude"][0, 0] - coord["Latitude"][1, 0]) ** 2)
+            clon, clat = ctm_data[0].longitude, ctm_data[0].latitude
+            gs = np.sqrt(np.abs(clon[0, 0] - clon[0, 1]) ** 2 + np.abs(clat[0, 0] - clat[1, 0]) ** 2)
+            up = lambda c: np.stack([upscaler(clon, clat, c[z], coord, gs, thr)[2] for z in range(c.shape[0])])   # noqa: E731
+            pmid, prof, air = up(pmid), up(prof), up(air)
+        key = L2.vcd if sensor == "MOPITT" else L2.x_col
+        mv = np.full_like(L2.vcd, np.nan)
+        mx = np.full_like(L2.vcd, np.nan)
+        for i in range(key.shape[0]):
+            for j in range(key.shape[1]):
+                if np.isnan(key[i, j]):
+                    continue
+                if sensor == "MOPITT":
+                    mv[i, j], mx[i, j] = mopitt_pixel(pmid[:, i, j], prof[:, i, j], air[:, i, j], L2.pressure_mid[:, i, j],
+                                                      L2.averaging_kernels[:, i, j], L2.apriori_profile[:, i, j],
+                                                      L2.aprior_column[i, j], L2.apriori_surface[i, j])
+                else:
+                    mx[i, j] = gosat_pixel(pmid[:, i, j], prof[:, i, j], L2.pressure_mid[:, i, j],
+                                           L2.averaging_kernels[:, i, j], L2.apriori_profile[:, i, j], L2.pressure_weight[:, i, j])
+        if sensor == "MOPITT":
+            mv[np.isnan(L2.vcd)] = np.nan
+            mv[np.isinf(L2.vcd)] = np.nan
+        else:
+            mx[np.isinf(L2.x_col)] = np.nan
+            mx[np.isnan(L2.x_col)] = np.nan
+        L2.ctm_vcd, L2.ctm_xcol, L2.ctm_time_at_sat = mv, mx, tc[ci]
     return sat_data
 
 

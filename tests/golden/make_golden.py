@@ -286,6 +286,35 @@ def gen_amf_recal():
     save("amf_recal.npz", **out)
 
 
+def gen_ak_conv():
+    """ak_conv_mopitt / ak_conv_gosat (the satellite_opt counterpart of amf_recal) on the seeded cases of tests/amf_cases.py"""
+    from oisatgmi.ak_conv_mopitt import ak_conv_mopitt as REF_mopitt
+    from oisatgmi.ak_conv_gosat import ak_conv_gosat as REF_gosat
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.modules.setdefault("oisatgmi.synthetic", syn)
+    import importlib
+    spec2 = importlib.util.spec_from_file_location("amf_cases_build", os.path.join(ROOT, "tests", "amf_cases.py"))
+    src = open(os.path.join(ROOT, "tests", "amf_cases.py")).read().replace("from oisatgmi import synthetic as syn", "")
+    ns = {"syn": syn, "np": np}
+    exec(compile(src, "amf_cases.py", "exec"), ns)               # our own test helper, with our generators bound
+    out = {}
+    for tag, build in ns["akconv_cases"]().items():
+        sensor, ctm, sat = build()
+        fn = REF_mopitt if sensor == "MOPITT" else REF_gosat
+        with np.errstate(all="ignore"):
+            res = quiet(fn, [to_ref(c) for c in ctm], [to_ref(x) for x in sat])
+        k = 0
+        for r in res:
+            if r is None:
+                continue
+            out[f"{tag}_{k}_ctm_vcd"] = np.asarray(r.ctm_vcd, dtype=np.float64)
+            out[f"{tag}_{k}_ctm_xcol"] = np.asarray(r.ctm_xcol, dtype=np.float64)
+            out[f"{tag}_{k}_time"] = np.float64(r.ctm_time_at_sat)
+            k += 1
+        out[f"{tag}_n"] = k
+    save("ak_conv.npz", **out)
+
+
 def gen_records():
     out = {}
     for nm in ("satellite_amf", "satellite_opt", "satellite_ssmis", "ctm_model"):
@@ -298,6 +327,9 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["rbf"]:                   # only the (slow) type-3 file
         gen_interpolator_rbf()
         raise SystemExit(0)
+    if sys.argv[1:] == ["akconv"]:
+        gen_ak_conv()
+        raise SystemExit(0)
     gen_records()
     gen_oi("72x144", 72, 144, 1000, 1001, full=True)
     gen_oi("360x720", 360, 720, 10000, 2001, full=False)
@@ -309,4 +341,5 @@ if __name__ == "__main__":
     gen_interpolator()
     gen_interpolator_rbf()
     gen_amf_recal()
+    gen_ak_conv()
     print("done")

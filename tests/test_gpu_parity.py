@@ -395,6 +395,51 @@ def test_amf_recal_larger_against_oracle(ctx):
 # ------------------------------------------------------------------------------------------------
 # interpolator.py
 # ------------------------------------------------------------------------------------------------
+# ------------------------------------------------------------------------------------------------
+# averaging-kernel convolution (ak_conv_mopitt.py / ak_conv_gosat.py; driver.conv_ak)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["m_eccoh", "m_gmi64", "m_up", "g_eccoh", "g_gmi64", "g_up"])
+def test_ak_conv_matches_reference(ctx, golden, tag):
+    """Outputs of the reference's own ak_conv_mopitt / ak_conv_gosat (tests/golden/ak_conv.npz).  float64 model cubes:
+    same operation order, 1e-12.  float32 model cubes: NumPy evaluates np.log / np.log10 of float32 with few-ulp SIMD
+    routines, the device with the correctly rounded ones -> 1e-5 (as for amf_recal)."""
+    from amf_cases import akconv_cases, check_akconv_against_golden
+    from oisatgmi.ak_conv_mopitt import ak_conv_mopitt
+    from oisatgmi.ak_conv_gosat import ak_conv_gosat
+    sensor, ctm, sat = akconv_cases()[tag]()
+    res = (ak_conv_mopitt if sensor == "MOPITT" else ak_conv_gosat)(ctm, sat)
+    assert res[1] is None
+    check_akconv_against_golden(golden("ak_conv.npz"), tag, res, 1e-12 if tag.endswith("gmi64") else 1e-5)
+
+
+def test_ak_conv_then_average_and_oi(ctx):
+    """The optimal-estimation branch of run/job.py end to end on the device: conv_ak -> average -> oi('GOSAT'),
+    against the oracle's restatement of the same chain."""
+    import copy
+    from amf_cases import akconv_cases
+    sensor, ctm, sat = akconv_cases()["g_eccoh"]()
+    for s in sat:
+        if s is not None:
+            s.time = s.time.replace(month=5)
+    ref_sat = orc.ak_conv(copy.deepcopy(ctm), copy.deepcopy(sat), "GOSAT")
+    o = oisatgmi()
+
+    class R:
+        pass
+    o.reader_obj = R()
+    o.reader_obj.ctm_data, o.reader_obj.sat_data = ctm, sat
+    o.conv_ak("GOSAT")
+    o.average("2019-05-01", "2019-06-01")
+    want = orc.averaging("2019-05-01", "2019-06-01", type("RO", (), {"sat_data": ref_sat})(), cfg.satellite_amf, cfg.satellite_opt)
+    np.testing.assert_allclose(o.aux2, want[4], rtol=1e-5, equal_nan=True)             # mean model XCH4 (ctm_xcol)
+    np.testing.assert_allclose(o.aux1, want[3], rtol=1e-12, equal_nan=True)            # mean observed XCH4 (x_col)
+    o.oi("GOSAT", error_ctm=20.0)
+    Xa, Y, Sa, So = orc.driver_oi_inputs(None, None, want[1], want[3].copy(), want[4], "GOSAT", 20.0)
+    ref = orc.OI(Xa.copy(), Y, Sa, So, regularization_on=True)
+    assert np.isfinite(o.ctm_averaged_vcd_corrected).any()
+    np.testing.assert_allclose(o.ctm_averaged_vcd_corrected, ref[0], rtol=1e-5, equal_nan=True)
+
+
 def test_upscaler_matches_reference(ctx, golden):
     g = golden("upscaler.npz")
     X, Y, Z, gs = g["X"], g["Y"], g["Z"], float(g["grid_size"])

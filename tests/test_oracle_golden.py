@@ -138,6 +138,16 @@ def test_interpolator_type3_rbf(golden):
         np.testing.assert_allclose(o, g["single_out"], rtol=0, atol=1e-12 * np.nanmax(np.abs(g["single_out"])), equal_nan=True)
 
 
+@pytest.mark.parametrize("tag", ["m_eccoh", "m_gmi64", "m_up", "g_eccoh", "g_gmi64", "g_up"])
+def test_ak_conv(golden, tag):
+    """ak_conv_mopitt / ak_conv_gosat restatement against the reference's own outputs."""
+    from amf_cases import akconv_cases, check_akconv_against_golden
+    sensor, ctm, sat = akconv_cases()[tag]()
+    with np.errstate(all="ignore"):
+        res = orc.ak_conv(ctm, sat, sensor)
+    check_akconv_against_golden(golden("ak_conv.npz"), tag, res, 1e-13)
+
+
 def test_records_match_reference(golden):
     g = golden("records.npz")
     for nm in ("satellite_amf", "satellite_opt", "satellite_ssmis", "ctm_model"):
