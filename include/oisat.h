@@ -151,6 +151,13 @@ int oisat_ak_conv_gosat(oisat_ctx* h, int ctm_dtype, const void* ctm_pmid, const
                         const double* apriori_profile, const double* pressure_weight, int nzs,
                         const double* x_col, int64_t n, double* model_xcol);
 
+/* ---- model precipitable water for SSMIS: pwv_cal.py (driver.py:42-44 cal_pwv) ---------------------------------
+ * oisat_water_column: deltap*profile/g/10000 per level, left to right in `dtype` (:63,:70).
+ * oisat_pwv_sum: out = nansum_k(partial[k]/1000) level after level in `dtype`, NaN where the observation
+ * (double vcd[n]) is NaN or +/-inf (:96-98).  partial: dev [nz][n] (after the optional model upscaling). */
+int oisat_water_column(oisat_ctx* h, int dtype, const void* deltap, const void* profile, int64_t n, void* out);
+int oisat_pwv_sum(oisat_ctx* h, int dtype, const void* partial, int nz, const double* vcd, int64_t n, void* out);
+
 /* ---- regridding: interpolator.py:10-97 --------------------------------------------------------- */
 /* signal.convolve2d(Z, ones(ky,kx)/(kx*ky)^(1|2), boundary='symm', mode='same'),
  * interpolator.py:40-46,:72-76.  Z, out: dev Ny*Nx row-major.  variance != 0 -> /(kx*ky)^2. */

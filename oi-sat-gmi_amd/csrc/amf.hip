@@ -142,6 +142,36 @@ __global__ __launch_bounds__(256) void column_sum_kernel(const T* __restrict__ c
     }
 }
 
+// ---- model precipitable water (pwv_cal.py:60-99) -----------------------------------------------------
+// deltap*profile/g/10000.0, left to right in T (:63,:70)
+template <typename T>
+__global__ __launch_bounds__(256) void water_column_kernel(const T* __restrict__ deltap, const T* __restrict__ profile, int64_t n,
+                                                            T* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        T v = deltap[i] * profile[i];
+        v = v / T(9.80665);
+        v = v / T(10000.0);
+        out[i] = v;
+    }
+}
+
+// np.nansum(partial/1000.0, axis=0) level after level in T, then NaN where the observation is NaN or +/-inf (:96-98)
+template <typename T>
+__global__ __launch_bounds__(256) void pwv_sum_kernel(const T* __restrict__ partial, int nz, const double* __restrict__ vcd, int64_t n,
+                                                       T* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+        T s = T(0);
+        for (int k = 0; k < nz; ++k) {
+            const T v = partial[(int64_t)k * n + p] / T(1000.0);
+            if (v == v) s += v;
+        }
+        const double v0 = vcd[p];
+        out[p] = (v0 != v0 || v0 == __builtin_inf() || v0 == -__builtin_inf()) ? nan_of<T>() : s;
+    }
+}
+
 // ---- averaging-kernel convolution ------------------------------------------------------------------
 // interp1d(np.log(model pressure), model profile)(np.log(satellite pressure)) for one pixel: the model column is
 // sorted by log-pressure in the cubes' dtype T (stable, NaN last), a satellite level is located by binary search and
@@ -327,6 +357,32 @@ extern "C" int oisat_ak_conv_gosat(oisat_ctx* h, int ctm_dtype, const void* ctm_
         OISAT_LAUNCH(h, "ak_conv_gosat", (ak_conv_gosat_kernel<double>), grid, block, 0, (const double*)ctm_pmid,
                      (const double*)ctm_profile, nzc, sat_pmid, averaging_kernels, apriori_profile, pressure_weight, nzs, x_col, n,
                      model_xcol);
+    }
+    return OISAT_OK;
+}
+
+extern "C" int oisat_water_column(oisat_ctx* h, int dtype, const void* deltap, const void* profile, int64_t n, void* out) {
+    ARG_CHECK(h && deltap && profile && out && n > 0);
+    ARG_CHECK(dtype == OISAT_F32 || dtype == OISAT_F64);
+    const int grid = stream_grid(n, 256);
+    if (dtype == OISAT_F32) {
+        OISAT_LAUNCH(h, "water_column", (water_column_kernel<float>), dim3(grid), dim3(256), 0, (const float*)deltap,
+                     (const float*)profile, n, (float*)out);
+    } else {
+        OISAT_LAUNCH(h, "water_column", (water_column_kernel<double>), dim3(grid), dim3(256), 0, (const double*)deltap,
+                     (const double*)profile, n, (double*)out);
+    }
+    return OISAT_OK;
+}
+
+extern "C" int oisat_pwv_sum(oisat_ctx* h, int dtype, const void* partial, int nz, const double* vcd, int64_t n, void* out) {
+    ARG_CHECK(h && partial && vcd && out && n > 0 && nz >= 1);
+    ARG_CHECK(dtype == OISAT_F32 || dtype == OISAT_F64);
+    const int grid = stream_grid(n, 256);
+    if (dtype == OISAT_F32) {
+        OISAT_LAUNCH(h, "pwv_sum", (pwv_sum_kernel<float>), dim3(grid), dim3(256), 0, (const float*)partial, nz, vcd, n, (float*)out);
+    } else {
+        OISAT_LAUNCH(h, "pwv_sum", (pwv_sum_kernel<double>), dim3(grid), dim3(256), 0, (const double*)partial, nz, vcd, n, (double*)out);
     }
     return OISAT_OK;
 }

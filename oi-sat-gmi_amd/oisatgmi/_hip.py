@@ -56,6 +56,8 @@ SIGNATURES = {
     "oisat_ak_conv_mopitt": (C.c_int, [_c_ctx, C.c_int, _ptr, _ptr, _ptr, C.c_int, _ptr, _ptr, _ptr, C.c_int, _ptr, _ptr, _ptr, _i64,
                                        _ptr, _ptr]),
     "oisat_ak_conv_gosat": (C.c_int, [_c_ctx, C.c_int, _ptr, _ptr, C.c_int, _ptr, _ptr, _ptr, _ptr, C.c_int, _ptr, _i64, _ptr]),
+    "oisat_water_column": (C.c_int, [_c_ctx, C.c_int, _ptr, _ptr, _i64, _ptr]),
+    "oisat_pwv_sum": (C.c_int, [_c_ctx, C.c_int, _ptr, C.c_int, _ptr, _i64, _ptr]),
     "oisat_boxfilter_symm": (C.c_int, [_c_ctx, C.c_int, _ptr, _i64, _i64, C.c_int, C.c_int, C.c_int, _ptr]),
     "oisat_nn_query": (C.c_int, [_c_ctx, _ptr, _ptr, _i64, _ptr, _ptr, _i64, C.c_double, _ptr, _ptr]),
     "oisat_gather_mask": (C.c_int, [_c_ctx, C.c_int, _ptr, _i64, C.c_int, _ptr, _i64, _ptr]),

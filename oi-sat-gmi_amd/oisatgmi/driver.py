@@ -2,11 +2,10 @@
 
 Drop-in for the methods of ``oisatgmi/driver.py`` that lie on the optimal-interpolation path:
 ``average`` (:53-63), ``bias_correct`` (:65-106) and ``oi`` (:108-114), the two vertical operators
-feeding them -- ``recal_amf`` (:35-38) and ``conv_ak`` (:46-51) -- and the output stage ``write_to_nc``
+feeding them -- ``recal_amf`` (:35-38), ``cal_pwv`` (:42-44) and ``conv_ak`` (:46-51) -- and the output stage ``write_to_nc``
 (:156-227; same variables, the scaling-factor rule evaluated on the device), with the same attribute
-names set on ``self``.  The remaining methods of the reference's class (``read_data``, ``cal_pwv``,
-``reporting``, ``savedaily``) are file formats, plotting and a sensor-specific operator outside this
-path: they raise ``NotImplementedError`` here -- see INTEGRATION.md
+names set on ``self``.  The remaining methods of the reference's class (``read_data``, ``reporting``,
+``savedaily``) are file formats and plotting outside this path: they raise ``NotImplementedError`` here -- see INTEGRATION.md
 for binding the HIP path into the reference's own class instead.
 """
 from __future__ import annotations
@@ -149,8 +148,10 @@ class oisatgmi(object):
         from .amf_recal import amf_recal
         self.reader_obj.sat_data = amf_recal(self.reader_obj.ctm_data, self.reader_obj.sat_data)
 
-    def cal_pwv(self, *a, **k):
-        self._out_of_scope("cal_pwv")
+    def cal_pwv(self):
+        """driver.py:42-44 of the reference."""
+        from .pwv_cal import pwv_calculator
+        self.reader_obj.sat_data = pwv_calculator(self.reader_obj.ctm_data, self.reader_obj.sat_data)
 
     def conv_ak(self, sensor: str):
         """driver.py:46-51 of the reference."""

@@ -364,3 +364,19 @@ def opt_granules(ctm, nzs: int, k: int, seed: int, sensor: str = "MOPITT"):
                                  rng.lognormal(mean=4.2, sigma=0.2, size=(ny, nx)), xcol, pw, sensor))
     out.insert(1, None)
     return out
+
+
+def ssmis_granules(ctm, k: int, seed: int):
+    """``k`` gridded SSMIS water-vapour granules (``satellite_ssmis``) on the model grid for ``cal_pwv``."""
+    from .config import satellite_ssmis
+    rng = np.random.default_rng(seed)
+    lat2, lon2 = ctm[0].latitude, ctm[0].longitude
+    out = []
+    for g in range(k):
+        vcd = rng.uniform(5.0, 60.0, size=lat2.shape)
+        vcd[rng.uniform(size=vcd.shape) < 0.2] = np.nan
+        vcd[1, 2] = np.inf
+        out.append(satellite_ssmis(vcd, rng.uniform(0.5, 3.0, size=lat2.shape), _dt.datetime(2019, 5, 2 + g, 6, 0), lat2, lon2,
+                                   False, [], 'SSMIS'))
+    out.insert(1, None)
+    return out

@@ -13,7 +13,7 @@ Pinning status ("Oracle"):
   ``tests/golden/*.npz`` hold outputs of the reference's own functions, produced in the build
   container by ``tests/golden/make_golden.py`` importing the reference modules.
 * ``amf_recal`` and ``ak_conv`` (MOPITT / GOSAT averaging-kernel convolution) are PINNED the same way
-  (``amf_recal.npz``, ``ak_conv.npz``).
+  (``amf_recal.npz``, ``ak_conv.npz``), and so is ``pwv_calculator`` (``pwv.npz``).
 * The knee index chosen from that curve comes from the third-party package ``kneed==0.8.3``
   (requirements.txt:9; call site optimal_interpolation.py:37-39), which is neither vendored in the
   reference nor installed here: ``kneedle_knee`` restates its published algorithm and is
@@ -578,6 +578,38 @@ def ak_conv(ctm_data, sat_data, sensor):
             mx[np.isinf(L2.x_col)] = np.nan
             mx[np.isnan(L2.x_col)] = np.nan
         L2.ctm_vcd, L2.ctm_xcol, L2.ctm_time_at_sat = mv, mx, tc[ci]
+    return sat_data
+
+
+def pwv_calculator(ctm_data, sat_data):
+    """``pwv_calculator`` (pwv_cal.py:7-101): model precipitable water for SSMIS.  Mutates and returns ``sat_data``."""
+    tc = np.array([_flat_time(t) for rec in ctm_data for t in rec.time])
+    for L2 in sat_data:
+        if L2 is None:
+            continue
+        ts = L2.time.year * 10000 + L2.time.month * 100 + L2.time.day
+        ci = int(np.argmin(np.abs(ts - tc))) if not ctm_data[0].averaged else 0
+        rec = ctm_data[ci]
+        if rec.ctmtype in ("ECCOH", "FREE"):
+            delp, prof = rec.delta_p.squeeze(), rec.gas_profile.squeeze()
+        elif rec.ctmtype == "GMI":
+            with np.errstate(all="ignore"):
+                prof = np.nanmean(rec.gas_profile, axis=0).squeeze()
+                delp = np.nanmean(rec.delta_p, axis=0).squeeze()
+        else:
+            raise NameError("ctm_deltap is not defined for ctmtype " + str(rec.ctmtype))
+        pc = delp * prof / 9.80665 / 10000.0
+        if L2.ctm_upscaled_needed:
+            coord = {"Longitude": L2.longitude_center, "Latitude": L2.latitude_center}
+            thr = np.sqrt(np.abs(coord["Longitude"][0, 0] - coord["Longitude"][0, 1]) ** 2 +
+                          np.abs(coord["Latitude"][0, 0] - coord["Latitude"][1, 0]) ** 2)
+            clon, clat = ctm_data[0].longitude, ctm_data[0].latitude
+            gs = np.sqrt(np.abs(clon[0, 0] - clon[0, 1]) ** 2 + np.abs(clat[0, 0] - clat[1, 0]) ** 2)
+            pc = np.stack([upscaler(clon, clat, pc[z], coord, gs, thr)[2] for z in range(pc.shape[0])])
+        pwv = np.nansum(pc / 1000.0, axis=0).squeeze()
+        pwv[np.isnan(L2.vcd)] = np.nan
+        pwv[np.isinf(L2.vcd)] = np.nan
+        L2.ctm_vcd = pwv
     return sat_data
 
 

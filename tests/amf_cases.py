@@ -71,6 +71,43 @@ def akconv_cases():
     return {"m_eccoh": m_eccoh, "m_gmi64": m_gmi64, "m_up": m_up, "g_eccoh": g_eccoh, "g_gmi64": g_gmi64, "g_up": g_up}
 
 
+def pwv_cases():
+    """name -> (ctm_data, sat_data) for the SSMIS precipitable-water operator (pwv_cal.py)"""
+    def eccoh():
+        ctm = syn.ctm_monthly(10, 14, 15, 2, 9701, ctmtype="ECCOH")
+        return ctm, syn.ssmis_granules(ctm, 3, 9702)
+
+    def gmi64():
+        import datetime
+        ctm = syn.ctm_monthly(8, 9, 12, 1, 9711, ctmtype="GMI", dtype=np.float64)
+        sat = syn.ssmis_granules(ctm, 2, 9712)
+        for s in sat:
+            if s is not None:
+                s.time = datetime.datetime(2019, 5, 1, 6, 0)      # slot 0 must be the closest: see akconv_cases
+        return ctm, sat
+
+    def up():
+        ctm = syn.ctm_monthly(49, 65, 6, 1, 9721, ctmtype="FREE", lat0=-12.0, lat1=12.0, lon0=-16.0, lon1=16.0)
+        coarse = syn.ctm_monthly(9, 11, 6, 1, 9722, ctmtype="FREE", lat0=-10.0, lat1=10.0, lon0=-12.5, lon1=12.5)
+        sat = syn.ssmis_granules(coarse, 2, 9723)
+        for s in sat:
+            if s is not None:
+                s.ctm_upscaled_needed = True
+        return ctm, sat
+    return {"eccoh": eccoh, "gmi64": gmi64, "up": up}
+
+
+def check_pwv_against_golden(g, tag, sat, rtol):
+    k = 0
+    for r in sat:
+        if r is None:
+            continue
+        np.testing.assert_allclose(np.asarray(r.ctm_vcd, dtype=np.float64), g[f"{tag}_{k}_ctm_vcd"], rtol=rtol, atol=0,
+                                   equal_nan=True, err_msg=f"{tag} granule {k}")
+        k += 1
+    assert k == int(g[f"{tag}_n"])
+
+
 def check_akconv_against_golden(g, tag, sat, rtol):
     k = 0
     for r in sat:

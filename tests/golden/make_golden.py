@@ -315,6 +315,27 @@ def gen_ak_conv():
     save("ak_conv.npz", **out)
 
 
+def gen_pwv():
+    """pwv_calculator (SSMIS branch of run/job.py:69-70) on the seeded cases of tests/amf_cases.py"""
+    from oisatgmi.pwv_cal import pwv_calculator as REF_pwv
+    src = open(os.path.join(ROOT, "tests", "amf_cases.py")).read().replace("from oisatgmi import synthetic as syn", "")
+    ns = {"syn": syn, "np": np}
+    exec(compile(src, "amf_cases.py", "exec"), ns)
+    out = {}
+    for tag, build in ns["pwv_cases"]().items():
+        ctm, sat = build()
+        with np.errstate(all="ignore"):
+            res = quiet(REF_pwv, [to_ref(c) for c in ctm], [to_ref(x) for x in sat])
+        k = 0
+        for r in res:
+            if r is None:
+                continue
+            out[f"{tag}_{k}_ctm_vcd"] = np.asarray(r.ctm_vcd, dtype=np.float64)
+            k += 1
+        out[f"{tag}_n"] = k
+    save("pwv.npz", **out)
+
+
 def gen_records():
     out = {}
     for nm in ("satellite_amf", "satellite_opt", "satellite_ssmis", "ctm_model"):
@@ -330,6 +351,9 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["akconv"]:
         gen_ak_conv()
         raise SystemExit(0)
+    if sys.argv[1:] == ["pwv"]:
+        gen_pwv()
+        raise SystemExit(0)
     gen_records()
     gen_oi("72x144", 72, 144, 1000, 1001, full=True)
     gen_oi("360x720", 360, 720, 10000, 2001, full=False)
@@ -342,4 +366,5 @@ if __name__ == "__main__":
     gen_interpolator_rbf()
     gen_amf_recal()
     gen_ak_conv()
+    gen_pwv()
     print("done")

@@ -412,6 +412,27 @@ def test_ak_conv_matches_reference(ctx, golden, tag):
     check_akconv_against_golden(golden("ak_conv.npz"), tag, res, 1e-12 if tag.endswith("gmi64") else 1e-5)
 
 
+@pytest.mark.parametrize("tag", ["eccoh", "gmi64", "up"])
+def test_pwv_matches_reference(ctx, golden, tag):
+    """pwv_calculator (pwv_cal.py) against the reference's own outputs; float32 model cubes are summed in float32 in
+    the same order, so both dtypes agree to rounding."""
+    from amf_cases import pwv_cases, check_pwv_against_golden
+    from oisatgmi.pwv_cal import pwv_calculator
+    ctm, sat = pwv_cases()[tag]()
+    res = pwv_calculator(ctm, sat)
+    assert res[1] is None
+    check_pwv_against_golden(golden("pwv.npz"), tag, res, 1e-12 if tag != "eccoh" else 1e-6)
+    # SSMIS branch of run/job.py: cal_pwv -> average -> oi; records of the third kind get NaN aux fields (averaging.py:89-91)
+    o = oisatgmi()
+    o.reader_obj = type("RO", (), {})()
+    o.reader_obj.ctm_data, o.reader_obj.sat_data = pwv_cases()[tag]()
+    o.cal_pwv()
+    o.average("2019-05-01", "2019-06-01")
+    assert np.isnan(o.aux1).all() and np.isfinite(o.ctm_averaged_vcd).any()
+    o.oi("SSMIS", error_ctm=30.0)
+    assert np.isfinite(o.ctm_averaged_vcd_corrected).any()
+
+
 def test_ak_conv_then_average_and_oi(ctx):
     """The optimal-estimation branch of run/job.py end to end on the device: conv_ak -> average -> oi('GOSAT'),
     against the oracle's restatement of the same chain."""

@@ -148,6 +148,13 @@ def test_ak_conv(golden, tag):
     check_akconv_against_golden(golden("ak_conv.npz"), tag, res, 1e-13)
 
 
+@pytest.mark.parametrize("tag", ["eccoh", "gmi64", "up"])
+def test_pwv(golden, tag):
+    from amf_cases import pwv_cases, check_pwv_against_golden
+    ctm, sat = pwv_cases()[tag]()
+    check_pwv_against_golden(golden("pwv.npz"), tag, orc.pwv_calculator(ctm, sat), 1e-13)
+
+
 def test_records_match_reference(golden):
     g = golden("records.npz")
     for nm in ("satellite_amf", "satellite_opt", "satellite_ssmis", "ctm_model"):
