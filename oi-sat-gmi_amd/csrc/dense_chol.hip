@@ -645,7 +645,14 @@ int potrf_lookahead(oisat_ctx* h, float* S, int64_t ld, int64_t nb, float* tinv,
     // panels of `pw` diagonal blocks: panel q covers block columns [q*pw, min((q+1)*pw, nb)); a panel is factored
     // (all rows below included) by the recursive routine on the main stream, its trailing update has K = pw*128
     const int64_t np = cdiv(nb, pw);
-    if (!h->aux_stream) HIP_TRY(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
+    if (!h->aux_stream) {
+        // lowest priority: the bulk updates must not sit in front of the panel chain when a CU slot frees up
+        int prio_low = 0, prio_high = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+        const char* pe = getenv("OISAT_AUX_PRIORITY");
+        const int prio = pe ? atoi(pe) : prio_low;
+        HIP_TRY(hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, prio));
+    }
     while ((int64_t)h->sync_events.size() < 2 * np + 2) {
         hipEvent_t ev;
         HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -767,9 +774,11 @@ extern "C" int oisat_potrf(oisat_ctx* h, float* S, int64_t m, int64_t ld, int* i
         OISAT_LAUNCH(h, "pad_identity", pad_identity_kernel, dim3(stream_grid((mp - m) * mp, 256)), dim3(256), 0, S, ld, m, mp);
     }
     // schedule: recursive by default.  The two-stream look-ahead schedule (OISAT_POTRF=lookahead[:panel blocks]) is
-    // kept selectable: measured at m = 1e4 it only ties the recursive one (12.6-12.9 ms vs 12.8 ms per analysis) --
-    // the trailing-update launches fill every CU slot, so the panel chain's small kernels queue behind ~20 us
-    // GEMM workgroups instead of overlapping them.
+    // kept selectable: measured at m = 1e4 it only ties the recursive one (12.7 ms per analysis either way).  The
+    // rocprofv3 timeline shows why: the first potrf_diag after a bulk update is dispatched at once but runs 300-350 us
+    // instead of 34 -- its workgroup needs 137 KB of LDS, a CU holding even one 74 KB gemm_nt workgroup cannot take
+    // it, and freed slots are refilled by the bulk launch until that launch drains; stream priority does not change
+    // this (nothing is preempted, and the slot that frees is never big enough).  See DESIGN.md section 4.
     bool lookahead = false;
     int64_t pw = 4;
     if (const char* env = getenv("OISAT_POTRF")) {
