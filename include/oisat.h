@@ -244,22 +244,27 @@ int oisat_potrf(oisat_ctx* h, float* S, int64_t m, int64_t ld, int* info_host);
 /* z <- L^-T L^-1 z  (dev double[m], fp32 factor, double accumulation). */
 int oisat_potrs(oisat_ctx* h, const float* L, int64_t m, int64_t ld, double* z_inout);
 
-/* r = d - (C.*sig sig^T + diag(var)) z  evaluated in double on the fly (iterative refinement). */
+/* r = d - (C.*sig sig^T + diag(var)) z  evaluated in double on the fly (iterative refinement).
+ * olat_sorted (may be NULL): dev double[m], latitudes of the observations in degrees, valid only if the
+ * observations are stored in ASCENDING latitude order; pairs whose latitudes differ by more than the angle at
+ * which exp(-g chord^2) < 2^-64 are then skipped (one contiguous column range per block of rows). */
 int oisat_cov_residual(oisat_ctx* h, const double* oxyz, const double* osig, const double* ovar, int64_t m,
-                       double g, const double* d, const double* z, double* r_out);
+                       double g, const double* d, const double* z, double* r_out, const double* olat_sorted);
 
 /* Solve (H B H^T + R) z = d: potrs + `refine` rounds of double-residual refinement.
  * resid_host (may be NULL): relative residual norms, refine+1 entries. */
 int oisat_gain_solve(oisat_ctx* h, const float* L, const double* oxyz, const double* osig, const double* ovar,
                      int64_t m, int64_t ld, double g, const double* d, int refine, double* z_out,
-                     double* resid_host);
+                     double* resid_host, const double* olat_sorted /* as for oisat_cov_residual; may be NULL */);
 
 /* inc_i = sig_i * sum_a C(i,a) osig_a z_a  (= row i of B H^T times z);  xa = xb + inc.
  * gxyz: dev double[3*n]; gsig: dev double[n]; z: dev double[m].  xb/xa/inc of `dtype`
- * (either of xa, inc may be NULL). */
+ * (either of xa, inc may be NULL).  glat (dev double[n], degrees) and olat_sorted (as for oisat_cov_residual)
+ * enable the latitude window: a block of cells only visits the observations within its latitude span +/- the
+ * cut-off angle.  Either may be NULL: every pair is evaluated. */
 int oisat_apply_increment(oisat_ctx* h, int dtype, const double* gxyz, const double* gsig, int64_t n,
                           const double* oxyz, const double* osig, const double* z, int64_t m, double g,
-                          const void* xb, void* xa, void* inc);
+                          const void* xb, void* xa, void* inc, const double* glat, const double* olat_sorted);
 
 /* X <- X L^-T for nrows (multiple of 128) extra rows, X: dev float[nrows][ldx], ldx >= roundup(m,128).
  * Same MFMA GEMMs as the factorization (block forward substitution with the inverted diagonal blocks).

@@ -825,10 +825,11 @@ extern "C" int oisat_potrs(oisat_ctx* h, const float* L, int64_t m, int64_t ld, 
 }
 
 extern "C" int oisat_cov_residual(oisat_ctx* h, const double* oxyz, const double* osig, const double* ovar, int64_t m, double g,
-                                  const double* d, const double* z, double* r_out);
+                                  const double* d, const double* z, double* r_out, const double* olat_sorted);
 
 extern "C" int oisat_gain_solve(oisat_ctx* h, const float* L, const double* oxyz, const double* osig, const double* ovar, int64_t m,
-                                int64_t ld, double g, const double* d, int refine, double* z_out, double* resid_host) {
+                                int64_t ld, double g, const double* d, int refine, double* z_out, double* resid_host,
+                                const double* olat_sorted) {
     ARG_CHECK(h && L && oxyz && osig && ovar && d && z_out && m > 0 && refine >= 0 && refine <= 8);
     ARG_CHECK(h->factor.S == L && h->factor.m == m && h->factor.ld == ld);
     double* r = (double*)oisat_ws(h, 6, sizeof(double) * (m + 16));
@@ -849,7 +850,7 @@ extern "C" int oisat_gain_solve(oisat_ctx* h, const float* L, const double* oxyz
     if (rc) return rc;
     for (int it = 0; it <= refine; ++it) {
         if (it == refine && !resid_host) break;
-        rc = oisat_cov_residual(h, oxyz, osig, ovar, m, g, d, z_out, r);
+        rc = oisat_cov_residual(h, oxyz, osig, ovar, m, g, d, z_out, r, olat_sorted);
         if (rc) return rc;
         if (resid_host) {
             OISAT_LAUNCH(h, "sumsq", sumsq_kernel, dim3(1), dim3(1024), 0, (const double*)r, m, nrm_dev);

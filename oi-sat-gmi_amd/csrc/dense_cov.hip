@@ -64,12 +64,33 @@ __global__ __launch_bounds__(256) void innovation_kernel(const T* __restrict__ x
     for (int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; a < m; a += stride) d[a] = y[a] - (double)xb[cell[a]];
 }
 
+// ---- latitude window ----------------------------------------------------------------------------------
+// exp2(-g2 d^2) < 2^-64 once the chord d exceeds sqrt(64/g2): such a pair changes a double sum by less than its
+// last bit times the cancellation factor, and two points whose latitudes differ by more than the matching angle are
+// at least that far apart.  With the observations sorted by latitude the pairs worth evaluating for a block of rows /
+// cells are therefore one contiguous index range, found by two binary searches.  (3.6x fewer pairs at L = 300 km.)
+__host__ __device__ inline double lat_window_deg(double g2) {
+    const double chord = sqrt(64.0 / g2);
+    return chord >= 2.0 ? 1e9 : 2.0 * asin(0.5 * chord) * 57.29577951308232;
+}
+
+__device__ __forceinline__ int64_t lower_bound_lat(const double* __restrict__ a, int64_t n, double v) {   // first i with a[i] >= v
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (a[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
 // ---- r = d - S z in double, S regenerated on the fly (iterative refinement) ----------------------
 // Block = 64 rows; 256 threads = 64 rows x 4 column phases; fixed-order combine (deterministic).
+// olat (optional): latitudes of the observations in degrees, ASCENDING -- the block's rows then span
+// [olat[row0], olat[row_last]] and only columns inside that span +/- the window are visited.
 __global__ __launch_bounds__(256) void cov_residual_kernel(const double* __restrict__ oxyz, const double* __restrict__ osig,
                                                             const double* __restrict__ ovar, int64_t m, double g,
                                                             const double* __restrict__ d, const double* __restrict__ z,
-                                                            double* __restrict__ r) {
+                                                            double* __restrict__ r, const double* __restrict__ olat, double win_deg) {
     __shared__ double sx[256], sy[256], sz[256], sw[256];      // chunk of 256 columns: coords and sig*z
     __shared__ double part[4][64];
     const int t = threadIdx.x;
@@ -77,8 +98,15 @@ __global__ __launch_bounds__(256) void cov_residual_kernel(const double* __restr
     const int64_t row = (int64_t)blockIdx.x * 64 + lr;
     const bool live = row < m;
     const double ax = live ? oxyz[row] : 0.0, ay = live ? oxyz[m + row] : 0.0, az = live ? oxyz[2 * m + row] : 0.0;
+    int64_t j0 = 0, j1 = m;
+    if (olat) {                                                 // block-uniform: every thread runs the same two searches
+        const int64_t r0 = (int64_t)blockIdx.x * 64, r1 = (r0 + 63 < m - 1) ? r0 + 63 : m - 1;
+        j0 = lower_bound_lat(olat, m, olat[r0] - win_deg);
+        j1 = lower_bound_lat(olat, m, olat[r1] + win_deg + 1e-9);
+        j0 &= ~(int64_t)255;                                    // keep the chunking aligned: same summation order per row
+    }
     double acc = 0.0;
-    for (int64_t c0 = 0; c0 < m; c0 += 256) {
+    for (int64_t c0 = j0; c0 < j1; c0 += 256) {
         const int64_t c = c0 + t;
         __syncthreads();
         if (c < m) {
@@ -115,9 +143,13 @@ __global__ __launch_bounds__(256) void apply_increment_kernel(const double* __re
                                                                int64_t n, const double* __restrict__ oxyz,
                                                                const double* __restrict__ osig, const double* __restrict__ z,
                                                                int64_t m, float g2,
-                                                               const T* __restrict__ xb, T* __restrict__ xa, T* __restrict__ inc) {
+                                                               const T* __restrict__ xb, T* __restrict__ xa, T* __restrict__ inc,
+                                                               const double* __restrict__ glat, const double* __restrict__ olat,
+                                                               double win_deg) {
     constexpr int CH = 512;
     __shared__ double2 sxy[CH], szw[CH];                    // (x, y) and (z, sig*z_solve)
+    __shared__ double s_lo[4], s_hi[4];
+    __shared__ int64_t s_j[2];
     const int t = threadIdx.x;
     double px[CELLS], py[CELLS], pz[CELLS];
     double acc[CELLS];
@@ -131,11 +163,31 @@ __global__ __launch_bounds__(256) void apply_increment_kernel(const double* __re
         pz[q] = live ? gxyz[2 * n + cell[q]] : 0.0;
         acc[q] = 0.0;
     }
-    for (int64_t c0 = 0; c0 < m; c0 += CH) {
+    int64_t j0 = 0, j1 = m;
+    if (glat && olat) {                                     // latitude span of this block's cells -> observation index range
+        double lo = 1e9, hi = -1e9;
+#pragma unroll
+        for (int q = 0; q < CELLS; ++q)
+            if (cell[q] < n) { const double la = glat[cell[q]]; lo = fmin(lo, la); hi = fmax(hi, la); }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { lo = fmin(lo, __shfl_xor(lo, o, kWave)); hi = fmax(hi, __shfl_xor(hi, o, kWave)); }
+        if ((t & 63) == 0) { s_lo[t >> 6] = lo; s_hi[t >> 6] = hi; }
+        __syncthreads();
+        if (t == 0) {
+            lo = fmin(fmin(s_lo[0], s_lo[1]), fmin(s_lo[2], s_lo[3]));
+            hi = fmax(fmax(s_hi[0], s_hi[1]), fmax(s_hi[2], s_hi[3]));
+            s_j[0] = lower_bound_lat(olat, m, lo - win_deg);
+            s_j[1] = lower_bound_lat(olat, m, hi + win_deg + 1e-9);
+        }
+        __syncthreads();
+        j0 = s_j[0];
+        j1 = s_j[1];
+    }
+    for (int64_t c0 = j0; c0 < j1; c0 += CH) {
         __syncthreads();
         for (int j = t; j < CH; j += 256) {
             const int64_t c = c0 + j;
-            const bool live = c < m;
+            const bool live = c < j1;
             sxy[j] = live ? make_double2(oxyz[c], oxyz[m + c]) : make_double2(0.0, 0.0);
             szw[j] = live ? make_double2(oxyz[2 * m + c], osig[c] * z[c]) : make_double2(0.0, 0.0);
         }
@@ -191,28 +243,31 @@ extern "C" int oisat_innovation(oisat_ctx* h, int dtype, const void* xb, const i
 }
 
 extern "C" int oisat_cov_residual(oisat_ctx* h, const double* oxyz, const double* osig, const double* ovar, int64_t m, double g,
-                                  const double* d, const double* z, double* r_out) {
+                                  const double* d, const double* z, double* r_out, const double* olat_sorted) {
     ARG_CHECK(h && oxyz && osig && ovar && d && z && r_out && m > 0);
+    const double win = lat_window_deg(g * (double)kLog2e);
     OISAT_LAUNCH(h, "cov_residual", cov_residual_kernel, dim3((unsigned)cdiv(m, 64)), dim3(256), 0, oxyz, osig, ovar, m, g, d,
-                 z, r_out);
+                 z, r_out, win < 180.0 ? olat_sorted : (const double*)nullptr, win);
     return OISAT_OK;
 }
 
 extern "C" int oisat_apply_increment(oisat_ctx* h, int dtype, const double* gxyz, const double* gsig, int64_t n,
                                      const double* oxyz, const double* osig, const double* z, int64_t m, double g,
-                                     const void* xb, void* xa, void* inc) {
+                                     const void* xb, void* xa, void* inc, const double* glat, const double* olat_sorted) {
     ARG_CHECK(h && gxyz && gsig && oxyz && osig && z && n > 0 && m > 0 && (xa || inc));
     ARG_CHECK(!xa || xb);
     ARG_CHECK(dtype == OISAT_F32 || dtype == OISAT_F64);
     constexpr int CELLS = 2;
     const unsigned grid = (unsigned)cdiv(n, 256 * CELLS);
     const float g2 = (float)(g * (double)kLog2e);
+    const double win = lat_window_deg((double)g2);
+    if (!(win < 180.0) || !glat || !olat_sorted) { glat = nullptr; olat_sorted = nullptr; }
     if (dtype == OISAT_F32) {
         OISAT_LAUNCH(h, "apply_increment", (apply_increment_kernel<float, CELLS>), dim3(grid), dim3(256), 0, gxyz, gsig, n, oxyz,
-                     osig, z, m, g2, (const float*)xb, (float*)xa, (float*)inc);
+                     osig, z, m, g2, (const float*)xb, (float*)xa, (float*)inc, glat, olat_sorted, win);
     } else {
         OISAT_LAUNCH(h, "apply_increment", (apply_increment_kernel<double, CELLS>), dim3(grid), dim3(256), 0, gxyz, gsig, n,
-                     oxyz, osig, z, m, g2, (const double*)xb, (double*)xa, (double*)inc);
+                     oxyz, osig, z, m, g2, (const double*)xb, (double*)xa, (double*)inc, glat, olat_sorted, win);
     }
     return OISAT_OK;
 }

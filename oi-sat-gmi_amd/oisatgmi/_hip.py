@@ -74,14 +74,14 @@ SIGNATURES = {
     "oisat_gemm_nt": (C.c_int, [_c_ctx, _ptr, _i64, _ptr, _i64, _ptr, _i64, _i64, _i64, _i64, C.c_int, C.c_int]),
     "oisat_potrf": (C.c_int, [_c_ctx, _ptr, _i64, _i64, C.POINTER(C.c_int)]),
     "oisat_potrs": (C.c_int, [_c_ctx, _ptr, _i64, _i64, _ptr]),
-    "oisat_cov_residual": (C.c_int, [_c_ctx, _ptr, _ptr, _ptr, _i64, C.c_double, _ptr, _ptr, _ptr]),
+    "oisat_cov_residual": (C.c_int, [_c_ctx, _ptr, _ptr, _ptr, _i64, C.c_double, _ptr, _ptr, _ptr, _ptr]),
     "oisat_gain_solve": (C.c_int, [_c_ctx, _ptr, _ptr, _ptr, _ptr, _i64, _i64, C.c_double, _ptr, C.c_int, _ptr,
-                                   C.POINTER(C.c_double)]),
+                                   C.POINTER(C.c_double), _ptr]),
     "oisat_trsm_rows": (C.c_int, [_c_ctx, _ptr, _i64, _i64, _ptr, _i64, _i64]),
     "oisat_posterior_error": (C.c_int, [_c_ctx, _ptr, _i64, _i64, _ptr, _ptr, _i64, _i64, _i64, _ptr, _ptr, C.c_double, _i64, _ptr]),
     "oisat_gain_diag": (C.c_int, [_c_ctx, _ptr, _i64, _i64, _ptr, _i64, _ptr]),
     "oisat_apply_increment": (C.c_int, [_c_ctx, C.c_int, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i64, C.c_double, _ptr,
-                                        _ptr, _ptr]),
+                                        _ptr, _ptr, _ptr, _ptr]),
 }
 
 

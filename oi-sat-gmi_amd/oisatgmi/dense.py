@@ -64,6 +64,7 @@ class DenseAnalysis:
         self.mp_max = -(-self.max_obs // NB) * NB
         c = self.ctx
         self.gxyz = c.upload(unit_vectors(grid_lat, grid_lon))
+        self.glat = c.upload(np.ravel(grid_lat), dtype=np.float64)       # latitude window of apply_increment
         item = self.dt.itemsize
         self.fields = c.alloc(3 * self.n * item)            # xb | xa | inc
         self.gsig = c.alloc(self.n * 8)
@@ -72,6 +73,7 @@ class DenseAnalysis:
         self.osig = c.alloc(m * 8)
         self.ovar = c.alloc(m * 8)
         self.ocell = c.alloc(m * 8)
+        self.olat = c.alloc(m * 8)
         self.oy = c.alloc(m * 8)
         self.d = c.alloc(m * 8)
         self.z = c.alloc(m * 8)
@@ -99,11 +101,27 @@ class DenseAnalysis:
         c = self.ctx
         self.m = m
         self.mp = -(-m // NB) * NB
-        c.upload_into(self.oxyz.ptr, unit_vectors(obs_lat, obs_lon))
-        c.upload_into(self.osig.ptr, np.ravel(obs_sigma_b), dtype=np.float64)
-        c.upload_into(self.ovar.ptr, np.ravel(obs_var), dtype=np.float64)
-        c.upload_into(self.d.ptr, np.ravel(innovation), dtype=np.float64)
+        o = self._sort_by_latitude(obs_lat)
+        c.upload_into(self.oxyz.ptr, unit_vectors(np.ravel(obs_lat)[o], np.ravel(obs_lon)[o]))
+        c.upload_into(self.osig.ptr, np.ravel(obs_sigma_b)[o], dtype=np.float64)
+        c.upload_into(self.ovar.ptr, np.ravel(obs_var)[o], dtype=np.float64)
+        c.upload_into(self.d.ptr, np.ravel(innovation)[o], dtype=np.float64)
         self._direct_innovation = True
+
+    def _sort_by_latitude(self, obs_lat):
+        """Observations live on the device in ascending-latitude order: the pairs (cell, observation) and
+        (observation, observation) whose correlation is above 2^-64 are then contiguous index ranges, which is what the
+        latitude windows of ``oisat_apply_increment`` / ``oisat_cov_residual`` skip by.  Per-observation results
+        (``download_z``, ``gain_diag``) are handed back in the caller's order."""
+        lat = np.ravel(np.asarray(obs_lat, dtype=np.float64))
+        self._order = np.argsort(lat, kind="stable")
+        self.ctx.upload_into(self.olat.ptr, lat[self._order], dtype=np.float64)
+        return self._order
+
+    def _unsort(self, per_obs):
+        out = np.empty_like(per_obs)
+        out[self._order] = per_obs
+        return out
 
     def load_obs(self, obs_lat, obs_lon, obs_cell, obs_y, obs_var):
         self._direct_innovation = False
@@ -113,12 +131,13 @@ class DenseAnalysis:
         c = self.ctx
         self.m = m
         self.mp = -(-m // NB) * NB
-        cell = np.ascontiguousarray(obs_cell, dtype=np.int64)
-        c.upload_into(self.oxyz.ptr, unit_vectors(obs_lat, obs_lon))
+        o = self._sort_by_latitude(obs_lat)
+        cell = np.ascontiguousarray(np.ravel(obs_cell)[o], dtype=np.int64)
+        c.upload_into(self.oxyz.ptr, unit_vectors(np.ravel(obs_lat)[o], np.ravel(obs_lon)[o]))
         c.upload_into(self.osig.ptr, self._gsig_host[cell], dtype=np.float64)
-        c.upload_into(self.ovar.ptr, np.ravel(obs_var), dtype=np.float64)
+        c.upload_into(self.ovar.ptr, np.ravel(obs_var)[o], dtype=np.float64)
         c.upload_into(self.ocell.ptr, cell)
-        c.upload_into(self.oy.ptr, np.ravel(obs_y), dtype=np.float64)
+        c.upload_into(self.oy.ptr, np.ravel(obs_y)[o], dtype=np.float64)
 
     # ---- the hot path: everything below runs on the device, enqueued on the handle's stream
     def run(self, L_km: float, refine: int = 2, check_pd: bool = False, want_resid: bool = False):
@@ -134,9 +153,9 @@ class DenseAnalysis:
         c.check(lib.oisat_potrf(h, self.S.ptr, m, ld, C.byref(info) if check_pd else None))
         resid = (C.c_double * (refine + 1))() if want_resid else None
         c.check(lib.oisat_gain_solve(h, self.S.ptr, self.oxyz.ptr, self.osig.ptr, self.ovar.ptr, m, ld, g, self.d.ptr,
-                                     int(refine), self.z.ptr, resid))
+                                     int(refine), self.z.ptr, resid, self.olat.ptr))
         c.check(lib.oisat_apply_increment(h, self.code, self.gxyz.ptr, self.gsig.ptr, self.n, self.oxyz.ptr,
-                                          self.osig.ptr, self.z.ptr, m, g, xb, xa, inc))
+                                          self.osig.ptr, self.z.ptr, m, g, xb, xa, inc, self.glat.ptr, self.olat.ptr))
         return list(resid) if want_resid else None
 
     # ---- posterior diagnostics (after run(); they reuse the factor that run() left in HBM)
@@ -156,7 +175,7 @@ class DenseAnalysis:
         if not hasattr(self, "_ak"):
             self._ak = c.alloc(self.max_obs * 8)
         c.check(c.lib.oisat_gain_diag(c.h, self.S.ptr, self.m, self.mp, self.ovar.ptr, int(chunk_rows), self._ak.ptr))
-        return c.download(self._ak.ptr, (self.m,), np.float64)
+        return self._unsort(c.download(self._ak.ptr, (self.m,), np.float64))
 
     # ---- outputs
     def download(self):
@@ -164,9 +183,10 @@ class DenseAnalysis:
         return out[0], out[1]
 
     def download_z(self):
-        return self.ctx.download(self.z.ptr, (self.m,), np.float64)
+        return self._unsort(self.ctx.download(self.z.ptr, (self.m,), np.float64))
 
     def download_S(self):
+        """S (after ``run``: its Cholesky factor), rows/columns in the device's ascending-latitude order (``self._order``)."""
         return self.ctx.download(self.S.ptr, (self.mp, self.mp), np.float32)
 
     @staticmethod

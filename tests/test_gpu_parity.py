@@ -688,6 +688,49 @@ def test_dense_edge_sizes(ctx):
         assert info["residuals"][-1] < 1e-12
 
 
+@pytest.mark.parametrize("L", [150.0, 400.0, 3000.0])
+def test_latitude_window_equals_the_full_sum(ctx, L):
+    """oisat_apply_increment / oisat_cov_residual with the latitude window (observations sorted by latitude) against the
+    same entry points evaluating every pair: the skipped pairs are below 2^-64 of the largest term.  Observations
+    include both poles and the date line; L = 3000 km makes the window wider than the sphere (no culling at all)."""
+    lib = ctx.lib
+    rng = np.random.default_rng(31)
+    lat2, lon2 = syn.global_grid(90, 180)
+    n = lat2.size
+    m = 3000
+    olat = np.concatenate([rng.uniform(-90, 90, m - 40), np.full(10, 89.9), np.full(10, -89.9), rng.uniform(-5, 5, 20)])
+    olon = np.concatenate([rng.uniform(-180, 180, m - 20), np.tile([179.99, -179.99], 10)])
+    order = np.argsort(olat, kind="stable")
+    olat, olon = olat[order], olon[order]
+    g = dense.decay_constant(L)
+    gxyz = ctx.upload(dense.unit_vectors(lat2, lon2))
+    gsig = ctx.upload(rng.uniform(0.5, 2.0, n))
+    glat = ctx.upload(lat2.ravel())
+    oxyz = ctx.upload(dense.unit_vectors(olat, olon))
+    osig = ctx.upload(rng.uniform(0.5, 2.0, m))
+    ovar = ctx.upload(rng.uniform(0.1, 1.0, m))
+    z = ctx.upload(rng.normal(size=m))
+    d = ctx.upload(rng.normal(size=m))
+    olat_b = ctx.upload(olat)
+    xb = ctx.upload(rng.uniform(1, 5, n))
+    outs = []
+    for win in (False, True):
+        inc = ctx.alloc(n * 8)
+        r = ctx.alloc(m * 8)
+        ctx.check(lib.oisat_apply_increment(ctx.h, _hip.F64, gxyz.ptr, gsig.ptr, n, oxyz.ptr, osig.ptr, z.ptr, m, g, xb.ptr, None,
+                                            inc.ptr, glat.ptr if win else None, olat_b.ptr if win else None))
+        ctx.check(lib.oisat_cov_residual(ctx.h, oxyz.ptr, osig.ptr, ovar.ptr, m, g, d.ptr, z.ptr, r.ptr, olat_b.ptr if win else None))
+        outs.append((ctx.download(inc.ptr, (n,), np.float64), ctx.download(r.ptr, (m,), np.float64)))
+    (inc0, r0), (inc1, r1) = outs
+    assert np.abs(inc0).max() > 0
+    np.testing.assert_allclose(inc1, inc0, rtol=0, atol=1e-13 * np.abs(inc0).max())
+    np.testing.assert_allclose(r1, r0, rtol=0, atol=1e-13 * np.abs(r0).max())
+    # and against a float64 NumPy contraction of the same pairs
+    C = orc.gaussian_corr(orc.unit_vectors(lat2.ravel()[::37], lon2.ravel()[::37]), orc.unit_vectors(olat, olon), L)
+    want = ctx.download(gsig.ptr, (n,), np.float64)[::37] * (C @ (ctx.download(osig.ptr, (m,), np.float64) * ctx.download(z.ptr, (m,), np.float64)))
+    np.testing.assert_allclose(inc1[::37], want, rtol=0, atol=3e-6 * np.abs(want).max())       # v_exp_f32 inside
+
+
 @pytest.mark.parametrize("species", ["NO2", "HCHO", "O3"])
 def test_dense_analysis_per_species(ctx, species):
     """BASELINE config 5 shapes (control_omino2 / control_omihcho / control_omio3.yml): the three parameter sets
