@@ -651,7 +651,17 @@ int potrf_lookahead(oisat_ctx* h, float* S, int64_t ld, int64_t nb, float* tinv,
         HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
         const char* pe = getenv("OISAT_AUX_PRIORITY");
         const int prio = pe ? atoi(pe) : prio_low;
-        HIP_TRY(hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, prio));
+        // OISAT_AUX_FREE_CUS=k: keep the first k CUs (bits of the queue's CU mask) off limits for the bulk updates, so
+        // that the panel chain's one-workgroup kernels (137 KB of LDS: a whole CU) always find a home
+        const char* fe = getenv("OISAT_AUX_FREE_CUS");
+        const int nfree = fe ? atoi(fe) : 0;
+        if (nfree > 0 && nfree < h->cu_count) {
+            std::vector<uint32_t> mask((h->cu_count + 31) / 32, 0xffffffffu);
+            for (int b = 0; b < nfree; ++b) mask[b / 32] &= ~(1u << (b % 32));
+            HIP_TRY(hipExtStreamCreateWithCUMask(&h->aux_stream, (uint32_t)mask.size(), mask.data()));
+        } else {
+            HIP_TRY(hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, prio));
+        }
     }
     while ((int64_t)h->sync_events.size() < 2 * np + 2) {
         hipEvent_t ev;
