@@ -168,6 +168,88 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(float* C, int64_t ldc, 
     OISAT_EPI(acc11, 1, 1)
 }
 
+// ---- gemm_nt for launches that cannot fill the chip with 128x128 tiles ------------------------------
+// Deep in the recursion the updates are tall and thin (e.g. 71 x 2 blocks, K = 3 blocks): 141 tiles of 128x128 on
+// 512 workgroup slots, every workgroup alone on its CU for 12 K-tiles of ~2.3 us plus load/epilogue latency.  The
+// same launch cut into 64x64 tiles is 564 workgroups of a quarter of the work each, four per CU: ~2x faster.
+// 4 waves as 2x2, one 32x32 MFMA tile per wave, BK = 32, same LDS image rows (36-float stride), same k permutation
+// and per-element accumulation order as gemm_nt_kernel (bit-identical results).
+constexpr int SB = 64;
+__global__ __launch_bounds__(256) void gemm_nt_small_kernel(float* C, int64_t ldc, const float* A, int64_t lda,
+                                                             const float* __restrict__ B, int64_t ldb, int ntm, int ntn, int K,
+                                                             int mode, int lower) {
+    __shared__ __attribute__((aligned(16))) float lds[2][2][SB * LDSW];       // 36,864 B
+    // tile decode: column-major; in `lower` mode column c holds rows c .. ntm-1 (units of 64)
+    int ti, tj;
+    {
+        int rem = blockIdx.x;
+        if (!lower) { tj = rem / ntm; ti = rem - tj * ntm; }
+        else {
+            int c = 0;
+            while (rem >= ntm - c) { rem -= ntm - c; ++c; }
+            tj = c;
+            ti = c + rem;
+        }
+    }
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    const float* Ag = A + (int64_t)ti * SB * lda;
+    const float* Bg = B + (int64_t)tj * SB * ldb;
+    const int srow = t >> 3, sk = (t & 7) * 4;           // rows srow and srow+32, 16 bytes at k = sk
+    const float* Ap = Ag + (int64_t)srow * lda + sk;
+    const float* Bp = Bg + (int64_t)srow * ldb + sk;
+    float4 ra0, ra1, rb0, rb1;
+#define OISAT_SGLOAD(k0)                                                             \
+    do {                                                                             \
+        ra0 = *reinterpret_cast<const float4*>(Ap + (k0));                           \
+        ra1 = *reinterpret_cast<const float4*>(Ap + 32 * lda + (k0));                \
+        rb0 = *reinterpret_cast<const float4*>(Bp + (k0));                           \
+        rb1 = *reinterpret_cast<const float4*>(Bp + 32 * ldb + (k0));                \
+    } while (0)
+#define OISAT_SLSTORE(buf)                                                           \
+    do {                                                                             \
+        *reinterpret_cast<float4*>(&lds[buf][0][srow * LDSW + sk]) = ra0;            \
+        *reinterpret_cast<float4*>(&lds[buf][0][(srow + 32) * LDSW + sk]) = ra1;     \
+        *reinterpret_cast<float4*>(&lds[buf][1][srow * LDSW + sk]) = rb0;            \
+        *reinterpret_cast<float4*>(&lds[buf][1][(srow + 32) * LDSW + sk]) = rb1;     \
+    } while (0)
+    f32x16 acc = {0};
+    const int nkt = K / BK;
+    OISAT_SGLOAD(0);
+    OISAT_SLSTORE(0);
+    __syncthreads();
+    const int frow = lane & 31, fh = lane >> 5;
+    const int aoff = (wr * 32 + frow) * LDSW + 4 * fh, boff = (wc * 32 + frow) * LDSW + 4 * fh;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nkt;
+        if (more) OISAT_SGLOAD((kt + 1) * BK);
+        float4 fa[4], fb[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            fa[s4] = *reinterpret_cast<const float4*>(&lds[cur][0][aoff + 8 * s4]);
+            fb[s4] = *reinterpret_cast<const float4*>(&lds[cur][1][boff + 8 * s4]);
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s4].x, fb[s4].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s4].y, fb[s4].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s4].z, fb[s4].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s4].w, fb[s4].w, acc, 0, 0, 0);
+        }
+        if (more) OISAT_SLSTORE(cur ^ 1);
+        __syncthreads();
+    }
+    float* Cg = C + ((int64_t)ti * SB + wr * 32) * ldc + (int64_t)tj * SB + wc * 32;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * fh;
+        float* p = Cg + (int64_t)row * ldc + frow;
+        if (mode == 0) *p = *p - acc[e];
+        else *p = acc[e];
+    }
+}
+
 // ---- diagonal block: Cholesky + inverse of one 128x128 block, one workgroup, all in LDS ----------
 // Right-looking at 16-column granularity, 4 waves.  Per block column J:
 //   (1) wave 0 factors the 16x16 diagonal block in registers (lane = row, columns in VGPRs, pivots
@@ -592,6 +674,15 @@ int launch_gemm(oisat_ctx* h, const char* name, float* C, int64_t ldc, const flo
     const int ntm = (int)(M / NB), ntn = (int)(N / NB);
     const int64_t ntiles = lower ? (int64_t)ntn * ntm - (int64_t)ntn * (ntn - 1) / 2 : (int64_t)ntm * ntn;
     if (ntiles <= 0) return OISAT_OK;
+    // too few 128x128 tiles for the 512 workgroup slots: 64x64 tiles, four workgroups per CU.  Not for the in-place
+    // TRSM form (C aliases A, N == K == 128): a 64-wide tile would overwrite panel columns its row neighbour still reads.
+    static const int small_max = getenv("OISAT_SMALL_TILES") ? atoi(getenv("OISAT_SMALL_TILES")) : 700;
+    if (ntiles <= small_max && h->small_tiles && C != A) {
+        const int sm = (int)(M / SB), sn = (int)(N / SB);
+        const int64_t st = lower ? (int64_t)sn * sm - (int64_t)sn * (sn - 1) / 2 : (int64_t)sm * sn;
+        OISAT_LAUNCH(h, name, gemm_nt_small_kernel, dim3((unsigned)st), dim3(256), 0, C, ldc, A, lda, B, ldb, sm, sn, K, mode, lower);
+        return OISAT_OK;
+    }
     if (ntiles >= (int64_t)INT32_MAX) {
         oisat_set_error("gemm grid too large");
         return OISAT_EINVAL;
