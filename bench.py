@@ -124,7 +124,8 @@ def roofline_leg(ctx, plan, L, refine, psteps):
                        "FETCH x2 per the gfx950 note; bytes per gemm_nt launch, mean over the launches of one factorization)")
     roof = {
         "bound": "mfma",
-        "kernel": "gemm_nt_kernel (the syrk_gemm + trsm_gemm launches of one Cholesky factorization)",
+        "kernel": "gemm_nt_kernel + gemm_nt_small_kernel (the syrk_gemm + trsm_gemm launches of one Cholesky factorization; "
+                  "the 64x64-tile kernel takes the launches of <= 700 tiles, 0.9 % of the GEMM time at this size)",
         "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
         "traffic": traffic, "traffic_source": traffic_src,
         "algorithmic_flops_per_step": chol_flops, "kernel_ms_per_step": gemm_ms, "launches_per_step": gemm_launches,
