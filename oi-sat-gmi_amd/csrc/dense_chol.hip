@@ -462,11 +462,17 @@ __global__ __launch_bounds__(256) void pad_identity_kernel(float* __restrict__ S
 // registers while it waits), applies each update as soon as the producing workgroup has published
 // that piece of the solution, then multiplies by the inverted diagonal block and publishes its own
 // piece.  Tickets are drawn from an atomic counter, so a workgroup only ever waits on workgroups
-// that started before it: no assumption on dispatch order or residency.  Hand-off = write-through
-// (agent-scope relaxed atomic) payload stores, vmcnt drain, barrier, one flag store; the consumer
-// polls the flag relaxed from one lane, barriers, and reads the payload with agent-scope atomic
-// loads (cdna_hip_programming.md guideline 16, form R1 with every load sc1).  Spins are bounded.
+// that started before it: no assumption on dispatch order or residency.
+// Hand-off: the PAYLOAD IS THE FLAG.  The solution vector is pre-filled with a NaN bit pattern no
+// computation produces; the producer publishes its 128 doubles with agent-scope relaxed atomic
+// stores (each 8-byte store is self-contained, so no fence, no vmcnt drain, no separate flag), the
+// consumer's lanes each poll their own element with agent-scope atomic loads until it differs from
+// the pattern.  Agent-scope traffic bypasses the per-XCD L2s, ~2 us a round trip: this form costs
+// two of them per block step on the critical path, the flag-after-payload form it replaces cost
+// five (store, drain, flag store | flag poll, payload load) -- 11.5 -> 6 us per step.  Spins are bounded.
 constexpr int TLD = NB + 1;              // LDS tile row stride (odd: row- and column-walks are conflict-free)
+constexpr unsigned kTrsvFill32 = 0x7ff80badu;                         // hipMemsetD32 word
+constexpr unsigned long long kTrsvEmpty = 0x7ff80bad7ff80badull;      // a quiet NaN with that payload, both halves equal
 
 struct TrsvCtl {                         // zeroed by hipMemsetAsync before every sweep
     unsigned ticket;
@@ -486,36 +492,45 @@ struct TrsvCtl {                         // zeroed by hipMemsetAsync before ever
         q[0] = reg[p].x; q[1] = reg[p].y; q[2] = reg[p].z; q[3] = reg[p].w;                                    \
     }
 
-__device__ __forceinline__ bool wait_flag(unsigned* flag, TrsvCtl* ctl, unsigned* err_total, int tid, unsigned* lds_ok) {
-    if (tid == 0) {
-        unsigned ok = 1, spins = 0;
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+// threads 0..127 fetch one published double each into vec[]; returns false if a producer never showed up
+__device__ __forceinline__ bool wait_payload(const double* src, double* vec, TrsvCtl* ctl, unsigned* err_total, int tid,
+                                             unsigned* lds_ok) {
+    if (tid < NB) {
+        const unsigned long long* p = reinterpret_cast<const unsigned long long*>(src) + tid;
+        unsigned long long bits;
+        unsigned spins = 0;
+        while ((bits = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == kTrsvEmpty) {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 24) || __hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                __hip_atomic_store(&ctl->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                atomicAdd(err_total, 1u);                 // survives the per-sweep memset: read by checked solves
-                ok = 0;
+            ++spins;
+            if ((spins & 1023u) == 0u &&
+                (spins > (1u << 22) || __hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                if (__hip_atomic_exchange(&ctl->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+                    atomicAdd(err_total, 1u);             // survives the per-sweep memset: read by checked solves
+                *lds_ok = 0u;
                 break;
             }
         }
-        *lds_ok = ok;
+        vec[tid] = __builtin_bit_cast(double, bits);
     }
     __syncthreads();
     return *lds_ok != 0u;
 }
 
 // forward: L y = r.  transpose == 0.   backward: L^T z = y.  transpose == 1 (block index runs downwards).
+// sol must arrive filled with kTrsvEmpty.
 template <int TRANSPOSE>
 __global__ __launch_bounds__(256) void trsv_pipe_kernel(const float* __restrict__ L, int64_t ld, const float* __restrict__ tinv, int nb,
                                                          const double* __restrict__ rhs, double* __restrict__ sol,
-                                                         unsigned* __restrict__ flags, TrsvCtl* __restrict__ ctl,
-                                                         unsigned* __restrict__ err_total) {
+                                                         TrsvCtl* __restrict__ ctl, unsigned* __restrict__ err_total) {
     extern __shared__ __attribute__((aligned(16))) float tile[];        // [128][TLD]
     __shared__ double vec[NB], part[NB];
     __shared__ unsigned s_ticket, s_ok;
     const int tid = threadIdx.x;
     const int row = tid & (NB - 1), hf = tid >> 7;       // two threads per row: columns [64*hf, 64*hf+64)
-    if (tid == 0) s_ticket = atomicAdd(&ctl->ticket, 1u);
+    if (tid == 0) {
+        s_ticket = atomicAdd(&ctl->ticket, 1u);
+        s_ok = 1u;
+    }
     __syncthreads();
     const int tk = (int)s_ticket;                       // 0 .. nb-1 in start order
     const int b = TRANSPOSE ? nb - 1 - tk : tk;         // my block row (fwd) / block column (bwd)
@@ -529,18 +544,15 @@ __global__ __launch_bounds__(256) void trsv_pipe_kernel(const float* __restrict_
     if (nsteps > 0) { TILE_PREFETCH(base, ld) } else { TILE_PREFETCH(Tb, NB) }
     for (int step = 0; step <= nsteps; ++step) {
         const bool last = step == nsteps;               // last pass: multiply by the inverted diagonal block
+        TILE_STORE()                                    // this step's block: in LDS before the wait, off the critical path
         if (!last) {
             const int j = TRANSPOSE ? nb - 1 - step : step;
-            if (!wait_flag(&flags[j], ctl, err_total, tid, &s_ok)) return;
-            if (tid < NB) vec[tid] = __hip_atomic_load(&sol[(int64_t)j * NB + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else if (hf == 0) {
-            vec[row] = acc;
-        }
-        TILE_STORE()
-        __syncthreads();
-        if (!last) {
+            if (!wait_payload(sol + (int64_t)j * NB, vec, ctl, err_total, tid, &s_ok)) return;
             if (step + 1 < nsteps) { const float* nx = base + (int64_t)(step + 1) * hop; TILE_PREFETCH(nx, ld) }
             else { TILE_PREFETCH(Tb, NB) }
+        } else {
+            if (hf == 0) vec[row] = acc;
+            __syncthreads();
         }
         double u = 0.0;
         const int c0 = hf * 64;
@@ -559,9 +571,6 @@ __global__ __launch_bounds__(256) void trsv_pipe_kernel(const float* __restrict_
         }
     }
     if (hf == 0) __hip_atomic_store(&sol[(int64_t)b * NB + row], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(&flags[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __global__ __launch_bounds__(256) void axpy_kernel(double* __restrict__ z, const double* __restrict__ dz, int64_t m) {
@@ -800,21 +809,22 @@ int potrf_lookahead(oisat_ctx* h, float* S, int64_t ld, int64_t nb, float* tinv,
 
 int trsv_solve(oisat_ctx* h, const ChFactor& f, double* rhs_pad /* mp, overwritten with the solution */, double* tmp) {
     const int nb = (int)(f.mp / NB);
-    // control block: [TrsvCtl | flags[nb]] per sweep, two sweeps
-    const size_t ctl_bytes = ((sizeof(TrsvCtl) + sizeof(unsigned) * nb + 15) / 16) * 16;
-    // slot 7: [err_total (16 B, cleared by oisat_potrf) | sweep 0 control | sweep 1 control]
+    // slot 7: [err_total (16 B, cleared by oisat_potrf) | control block of sweep 0 | control block of sweep 1]
+    const size_t ctl_bytes = ((sizeof(TrsvCtl) + 15) / 16) * 16;
     char* base = (char*)oisat_ws(h, 7, 16 + 2 * ctl_bytes);
     if (!base) return OISAT_ENOMEM;
     unsigned* err_total = (unsigned*)base;
     char* ctl = base + 16;
     HIP_TRY(hipMemsetAsync(ctl, 0, 2 * ctl_bytes, h->stream));
     const size_t shm = sizeof(float) * NB * TLD;
-    // forward: L y = rhs   (y -> tmp)
+    // forward: L y = rhs   (y -> tmp, pre-filled with the "not yet published" pattern)
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)tmp, (int)kTrsvFill32, (size_t)f.mp * 2, h->stream));
     OISAT_LAUNCH(h, "trsv_fwd", (trsv_pipe_kernel<0>), dim3(nb), dim3(256), shm, f.S, f.ld, (const float*)f.tinv, nb,
-                 (const double*)rhs_pad, tmp, (unsigned*)(ctl + sizeof(TrsvCtl)), (TrsvCtl*)ctl, err_total);
-    // backward: L^T z = y  (z -> rhs_pad)
+                 (const double*)rhs_pad, tmp, (TrsvCtl*)ctl, err_total);
+    // backward: L^T z = y  (z -> rhs_pad; the forward sweep has consumed it by now, stream order)
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)rhs_pad, (int)kTrsvFill32, (size_t)f.mp * 2, h->stream));
     OISAT_LAUNCH(h, "trsv_bwd", (trsv_pipe_kernel<1>), dim3(nb), dim3(256), shm, f.S, f.ld, (const float*)f.tinv, nb,
-                 (const double*)tmp, rhs_pad, (unsigned*)(ctl + ctl_bytes + sizeof(TrsvCtl)), (TrsvCtl*)(ctl + ctl_bytes), err_total);
+                 (const double*)tmp, rhs_pad, (TrsvCtl*)(ctl + ctl_bytes), err_total);
     return OISAT_OK;
 }
 
