@@ -250,6 +250,76 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(float* C, int64_t ld
     }
 }
 
+// The in-place TRSM-as-GEMM (C aliases A, N == K == 128) cannot use 64-wide tiles: a tile would overwrite panel columns
+// its row neighbour still reads.  64 rows x all 128 columns per workgroup instead (each wave 32 x 64 = two MFMA tiles):
+// a workgroup owns whole rows and has read every K-tile of them before its epilogue writes.
+__global__ __launch_bounds__(256) void gemm_nt_rows64_kernel(float* C, int64_t ldc, const float* A, int64_t lda,
+                                                              const float* __restrict__ B, int64_t ldb, int K, int mode) {
+    __shared__ __attribute__((aligned(16))) float ldsA[2][SB * LDSW];        // 18,432 B
+    __shared__ __attribute__((aligned(16))) float ldsB[2][NB * LDSW];        // 36,864 B
+    const int ti = blockIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    const int srow = t >> 3, sk = (t & 7) * 4;
+    const float* Ap = A + ((int64_t)ti * SB + srow) * lda + sk;
+    const float* Bp = B + (int64_t)srow * ldb + sk;
+    float4 ra0, ra1, rb0, rb1, rb2, rb3;
+#define OISAT_RGLOAD(k0)                                                             \
+    do {                                                                             \
+        ra0 = *reinterpret_cast<const float4*>(Ap + (k0));                           \
+        ra1 = *reinterpret_cast<const float4*>(Ap + 32 * lda + (k0));                \
+        rb0 = *reinterpret_cast<const float4*>(Bp + (k0));                           \
+        rb1 = *reinterpret_cast<const float4*>(Bp + 32 * ldb + (k0));                \
+        rb2 = *reinterpret_cast<const float4*>(Bp + 64 * ldb + (k0));                \
+        rb3 = *reinterpret_cast<const float4*>(Bp + 96 * ldb + (k0));                \
+    } while (0)
+#define OISAT_RLSTORE(buf)                                                           \
+    do {                                                                             \
+        *reinterpret_cast<float4*>(&ldsA[buf][srow * LDSW + sk]) = ra0;              \
+        *reinterpret_cast<float4*>(&ldsA[buf][(srow + 32) * LDSW + sk]) = ra1;       \
+        *reinterpret_cast<float4*>(&ldsB[buf][srow * LDSW + sk]) = rb0;              \
+        *reinterpret_cast<float4*>(&ldsB[buf][(srow + 32) * LDSW + sk]) = rb1;       \
+        *reinterpret_cast<float4*>(&ldsB[buf][(srow + 64) * LDSW + sk]) = rb2;       \
+        *reinterpret_cast<float4*>(&ldsB[buf][(srow + 96) * LDSW + sk]) = rb3;       \
+    } while (0)
+    f32x16 acc0 = {0}, acc1 = {0};
+    const int nkt = K / BK;
+    OISAT_RGLOAD(0);
+    OISAT_RLSTORE(0);
+    __syncthreads();
+    const int frow = lane & 31, fh = lane >> 5;
+    const int aoff = (wr * 32 + frow) * LDSW + 4 * fh, boff = (wc * 64 + frow) * LDSW + 4 * fh;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nkt;
+        if (more) OISAT_RGLOAD((kt + 1) * BK);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const float4 a = *reinterpret_cast<const float4*>(&ldsA[cur][aoff + 8 * s4]);
+            const float4 b0 = *reinterpret_cast<const float4*>(&ldsB[cur][boff + 8 * s4]);
+            const float4 b1 = *reinterpret_cast<const float4*>(&ldsB[cur][boff + 32 * LDSW + 8 * s4]);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
+        }
+        if (more) OISAT_RLSTORE(cur ^ 1);
+        __syncthreads();
+    }
+    float* Cg = C + ((int64_t)ti * SB + wr * 32) * ldc + wc * 64;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * fh;
+        float* p = Cg + (int64_t)row * ldc + frow;
+        if (mode == 0) { p[0] = p[0] - acc0[e]; p[32] = p[32] - acc1[e]; }
+        else { p[0] = acc0[e]; p[32] = acc1[e]; }
+    }
+}
+
 // ---- diagonal block: Cholesky + inverse of one 128x128 block, one workgroup, all in LDS ----------
 // Right-looking at 16-column granularity, 4 waves.  Per block column J:
 //   (1) wave 0 factors the 16x16 diagonal block in registers (lane = row, columns in VGPRs, pivots
@@ -683,13 +753,17 @@ int launch_gemm(oisat_ctx* h, const char* name, float* C, int64_t ldc, const flo
     const int ntm = (int)(M / NB), ntn = (int)(N / NB);
     const int64_t ntiles = lower ? (int64_t)ntn * ntm - (int64_t)ntn * (ntn - 1) / 2 : (int64_t)ntm * ntn;
     if (ntiles <= 0) return OISAT_OK;
-    // too few 128x128 tiles for the 512 workgroup slots: 64x64 tiles, four workgroups per CU.  Not for the in-place
-    // TRSM form (C aliases A, N == K == 128): a 64-wide tile would overwrite panel columns its row neighbour still reads.
+    // too few 128x128 tiles for the 512 workgroup slots: 64x64 tiles, four workgroups per CU; the in-place TRSM form
+    // (C aliases A, N == K == 128) takes 64 x 128 tiles (gemm_nt_rows64_kernel).
     static const int small_max = getenv("OISAT_SMALL_TILES") ? atoi(getenv("OISAT_SMALL_TILES")) : 700;
     if (ntiles <= small_max && h->small_tiles && C != A) {
         const int sm = (int)(M / SB), sn = (int)(N / SB);
         const int64_t st = lower ? (int64_t)sn * sm - (int64_t)sn * (sn - 1) / 2 : (int64_t)sm * sn;
         OISAT_LAUNCH(h, name, gemm_nt_small_kernel, dim3((unsigned)st), dim3(256), 0, C, ldc, A, lda, B, ldb, sm, sn, K, mode, lower);
+        return OISAT_OK;
+    }
+    if (ntiles <= small_max && h->small_tiles && C == A && N == NB && !lower) {     // in-place TRSM-as-GEMM
+        OISAT_LAUNCH(h, name, gemm_nt_rows64_kernel, dim3((unsigned)(M / SB)), dim3(256), 0, C, ldc, A, lda, B, ldb, K, mode);
         return OISAT_OK;
     }
     if (ntiles >= (int64_t)INT32_MAX) {
