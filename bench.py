@@ -155,12 +155,20 @@ def tier_a_leg(ctx, ny, nx, nobs, sync):
     apply_ms = prof["oi_apply"]["total_ms"] / prof["oi_apply"]["launches"]
     curve_ms = prof["oi_curve"]["total_ms"] / prof["oi_curve"]["launches"]
     gbs = DiagOI.algorithmic_bytes(n, 4) / (apply_ms * 1e-3) / 1e9
+    # sweep: per cell and scaling t = Sa*s, K = t/(t+So), Sb = (1-K)*t, AK = 1 - Sb/t, sum/count -> 9 flop, two of them
+    # IEEE divisions (~10 VALU instructions each with -ffp-contract=off and no fast-math: the reference's arithmetic)
+    sweep_flops = 9.0 * 99 * n
+    sweep_tf = sweep_flops / (curve_ms * 1e-3) / 1e12
     return {"workload": f"OI(regularization_on=True) {ny}x{nx}, {nobs} observed cells, fp32, device-resident",
             "value": n * 50 / el, "unit": "grid-cells/s", "ms_per_call": 1e3 * el / 50,
             "ms_per_call_with_host_knee_pick": 1e3 * el_host / 20, "knee_index": int(idx),
             "kernel_ms": {k: v["total_ms"] / v["launches"] for k, v in prof.items()},
             "roofline_oi_apply": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes": DiagOI.algorithmic_bytes(n, 4)}}
+                                  "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes": DiagOI.algorithmic_bytes(n, 4)},
+            "roofline_oi_curve": {"bound": "valu (fp32 division)", "achieved": sweep_tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": sweep_tf / MFMA_F32_PEAK_TFLOPS, "algorithmic_flops": sweep_flops,
+                                  "note": "a division counted as one flop; peak = fp32 vector rate (157.3, packed); HBM side: "
+                                          "8 B/cell read once = %.1f GB/s" % (8.0 * n / (curve_ms * 1e-3) / 1e9)}}
 
 
 def tiled_leg(ctx, workload, sync):
