@@ -198,6 +198,39 @@ def test_oi_edge_shapes(ctx):
     assert oi_mod.last_regularization["index"] == 0 and all(np.isnan(a).all() for a in res)
 
 
+def test_oi_special_values_against_oracle(ctx):
+    """NaN / +-inf / 0 / negative / tiny values sprinkled into all four inputs: every output cell and its NaN-ness must
+    follow the reference arithmetic (optimal_interpolation.py:14-52: in-place clamp, 0/0 -> NaN AK with K = 0, inf
+    errors, ...), for a forced regularisation index and with regularisation off."""
+    specials = np.array([np.nan, np.inf, -np.inf, 0.0, -0.0, -3.0, 1e-300, 1e300, 5e-324])
+    for seed in range(6):
+        rng = np.random.default_rng(900 + seed)
+        shape = (int(rng.integers(1, 40)), int(rng.integers(1, 70)))
+        arrs = []
+        for lo, hi in ((0.2, 10.0), (-1.0, 10.0), (0.01, 25.0), (0.01, 1.0)):          # Xa, Y, Sa, So
+            a = rng.uniform(lo, hi, size=shape)
+            hit = rng.uniform(size=shape) < 0.15
+            a[hit] = rng.choice(specials, size=int(hit.sum()))
+            arrs.append(a)
+        Xa, Y, Sa, So = arrs
+        with np.errstate(all="ignore"):
+            for kw in (dict(regularization_on=False), dict(regularization_on=True, reg_index=37)):
+                ref = orc.OI(Xa.copy(), Y.copy(), Sa, So, regularization_on=kw["regularization_on"],
+                             forced_index=kw.get("reg_index"))
+                Yc = Y.copy()
+                res = OI(Xa.copy(), Yc, Sa, So, **kw)
+                for nm, a, b in zip(("Xb", "AK", "inc", "err"), res, ref[:4]):
+                    assert np.array_equal(np.isnan(a), np.isnan(b)), (seed, kw, nm)
+                    np.testing.assert_allclose(a, b, rtol=RT64, equal_nan=True, err_msg=f"seed {seed} {kw} {nm}")
+                assert not (Yc[~np.isnan(Yc)] < 0).any()                                # clamped in the caller's array
+    # the stacked reductions of averaging.py with the same specials
+    stack = np.random.default_rng(7).uniform(0.1, 2.0, size=(7, 9, 11))
+    hit = np.random.default_rng(8).uniform(size=stack.shape) < 0.25
+    stack[hit] = np.random.default_rng(9).choice(specials[:6], size=int(hit.sum()))
+    with np.errstate(all="ignore"):
+        np.testing.assert_allclose(error_averager(stack.copy()), orc.error_averager(stack.copy()), rtol=RT64, equal_nan=True)
+
+
 # ------------------------------------------------------------------------------------------------
 # averaging.py
 # ------------------------------------------------------------------------------------------------
