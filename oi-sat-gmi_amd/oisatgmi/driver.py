@@ -4,8 +4,8 @@ Drop-in for the methods of ``oisatgmi/driver.py`` that lie on the optimal-interp
 ``average`` (:53-63), ``bias_correct`` (:65-106) and ``oi`` (:108-114), the two vertical operators
 feeding them -- ``recal_amf`` (:35-38), ``cal_pwv`` (:42-44) and ``conv_ak`` (:46-51) -- and the output stage ``write_to_nc``
 (:156-227; same variables, the scaling-factor rule evaluated on the device), with the same attribute
-names set on ``self``.  The remaining methods of the reference's class (``read_data``, ``reporting``,
-``savedaily``) are file formats and plotting outside this path: they raise ``NotImplementedError`` here -- see INTEGRATION.md
+names set on ``self``; ``savedaily`` (:135-155) is plain file writing and is kept as is.  The remaining methods
+of the reference's class (``read_data``, ``reporting``) are file formats and plotting outside this path: they raise ``NotImplementedError`` here -- see INTEGRATION.md
 for binding the HIP path into the reference's own class instead.
 """
 from __future__ import annotations
@@ -165,6 +165,20 @@ class oisatgmi(object):
     def reporting(self, *a, **k):
         self._out_of_scope("reporting")
 
-    def savedaily(self, *a, **k):
-        self._out_of_scope("savedaily")
+    def savedaily(self, folder, gasname, date):
+        """Per-granule .mat dumps (driver.py:135-155 of the reference): host-side file writing only, same file names
+        and variable names; kept so that run/job.py's ``save_daily`` switch works with this facade."""
+        from scipy.io import savemat
+        if not os.path.exists(folder):
+            os.makedirs(folder)
+        first_valid_idx = next(i for i, sat_data in enumerate(self.reader_obj.sat_data) if sat_data is not None)
+        latitude = self.reader_obj.ctm_data[first_valid_idx].latitude
+        longitude = self.reader_obj.ctm_data[first_valid_idx].longitude
+        for counter, sat in enumerate(self.reader_obj.sat_data):
+            if sat is None:
+                continue
+            time_sat = 10000.0 * sat.time.year + 100.0 * sat.time.month + sat.time.day + sat.time.hour / 24.0
+            savemat(folder + "/" + "sat_data_" + gasname + "_" + str(time_sat) + str(counter) + ".mat",
+                    {"vcd_sat": sat.vcd, "vcd_ctm": sat.ctm_vcd, "vcd_err": sat.uncertainty, "time_sat": time_sat,
+                     "lat": latitude, "lon": longitude})
 

@@ -369,6 +369,8 @@ def test_driver_methods(ctx, golden):
     np.testing.assert_allclose(o2.ctm_averaged_vcd_corrected, ref[0], rtol=RT64, equal_nan=True)
     with pytest.raises(NotImplementedError):
         o.reporting("x", "NO2")
+    with pytest.raises(NotImplementedError):
+        o.read_data("GMI", ".", ["NO2"], "3-hourly", "OMI_NO2", ".", "201906")
     # output stage (driver.py:156-227): scaling-factor rule NaN/inf/0 -> 1 and the variable list
     post, prior = o.ctm_averaged_vcd_corrected.copy(), o.ctm_averaged_vcd.copy()
     obs = np.argwhere(np.isfinite(post))

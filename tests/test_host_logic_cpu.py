@@ -91,3 +91,24 @@ def test_synthetic_is_seeded():
     assert (a.Y[~np.isnan(a.Y)] < 0).sum() >= 0
     p = syn.point_obs_case(36, 72, 300, 3, swaths=True)
     assert p.obs_y.size <= 300 and np.all(np.abs(p.obs_lat) <= 90)
+
+
+def test_savedaily_writes_the_reference_files(tmp_path):
+    """driver.py:135-155: one .mat per granule, named and keyed as the reference does (host-only, no GPU)."""
+    import datetime
+    from scipy.io import loadmat
+    from oisatgmi.driver import oisatgmi
+    from oisatgmi import config as cfg
+    lat, lon = np.meshgrid(np.arange(3.0), np.arange(4.0), indexing="ij")
+    mk = lambda d: cfg.satellite_ssmis(np.full((3, 4), float(d)), np.ones((3, 4)), datetime.datetime(2019, 6, d, 12), lat, lon,
+                                       False, np.full((3, 4), 2.0 * d), "SSMIS")   # noqa: E731
+    o = oisatgmi()
+    o.reader_obj = type("RO", (), {})()
+    o.reader_obj.sat_data = [mk(1), None, mk(2)]
+    o.reader_obj.ctm_data = [cfg.ctm_model(lat, lon, [], [], [], [], [], "FREE", False)] * 3
+    o.savedaily(str(tmp_path / "daily"), "H2O", "2019_06")
+    files = sorted(p.name for p in (tmp_path / "daily").iterdir())
+    assert files == ["sat_data_H2O_20190601.50.mat", "sat_data_H2O_20190602.52.mat"]
+    m = loadmat(str(tmp_path / "daily" / files[1]))
+    assert set(("vcd_sat", "vcd_ctm", "vcd_err", "time_sat", "lat", "lon")) <= set(m)
+    np.testing.assert_array_equal(m["vcd_ctm"], np.full((3, 4), 4.0))
