@@ -116,11 +116,11 @@ def roofline_leg(ctx, plan, L, refine, psteps):
     chol_flops = m ** 3 / 3.0
     achieved = chol_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     traffic, traffic_src = None, None
-    tfile = os.path.join(ROOT, "profiles", "r01_c3_hbm_traffic_pmc.json")
+    tfile = os.path.join(ROOT, "profiles", "r01_f_c3_hbm_traffic_pmc.json")
     if m > 90000 and os.path.exists(tfile):       # PMC pass of this same workload (rocprofv3 --pmc, offline)
         tj = json.load(open(tfile))
         traffic = tj["hbm_bytes_per_factorization_corrected"] / tj["launches_per_factorization"]
-        traffic_src = ("profiles/r01_c3_hbm_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
+        traffic_src = ("profiles/r01_f_c3_hbm_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
                        "FETCH x2 per the gfx950 note; bytes per gemm_nt launch, mean over the launches of one factorization)")
     roof = {
         "bound": "mfma",

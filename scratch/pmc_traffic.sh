@@ -10,7 +10,8 @@ for tag, f in (("FETCH_SIZE", "gpurun_out/pmc_c3_fetch/f_counter_collection.csv"
     agg = collections.defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == tag:
-            k = r["Kernel_Name"].split("(")[0][-40:]
+            import re
+            mm = re.search(r"(\w+_kernel)", r["Kernel_Name"]); k = mm.group(1) if mm else r["Kernel_Name"][:40]
             agg[k][0] += float(r["Counter_Value"]); agg[k][1] += 1
     res[tag] = {k: {"sum_KiB": v[0], "dispatches": v[1]} for k, v in agg.items()}
 json.dump(res, open("gpurun_out/pmc_c3_traffic.json", "w"), indent=1)
