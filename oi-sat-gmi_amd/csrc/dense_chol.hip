@@ -938,19 +938,22 @@ extern "C" int oisat_potrf(oisat_ctx* h, float* S, int64_t m, int64_t ld, int* i
     float* tinv = (float*)oisat_ws(h, 3, sizeof(float) * mpb * NB * NB);
     int* info_dev = (int*)oisat_ws(h, 4, 256);
     if (!tinv || !info_dev) return OISAT_ENOMEM;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)potrf_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)(sizeof(float) * (2 * NB * LDA + 8 * DINV_SZ))));
-        HIP_TRY(hipFuncSetAttribute((const void*)trsv_pipe_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)(sizeof(float) * NB * TLD)));
-        HIP_TRY(hipFuncSetAttribute((const void*)trsv_pipe_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)(sizeof(float) * NB * TLD)));
-        attr_set = true;
-    }
+    // per-function attributes, set once per process (handles may be driven from different host threads)
+    static const hipError_t attr_rc = []() {
+        hipError_t e = hipFuncSetAttribute((const void*)potrf_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)(sizeof(float) * (2 * NB * LDA + 8 * DINV_SZ)));
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)trsv_pipe_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(sizeof(float) * NB * TLD));
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)trsv_pipe_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(sizeof(float) * NB * TLD));
+        return e;
+    }();
+    HIP_TRY(attr_rc);
     HIP_TRY(hipMemsetAsync(info_dev, 0, sizeof(int), h->stream));
     {
-        const size_t ctl_bytes = ((sizeof(TrsvCtl) + sizeof(unsigned) * mpb + 15) / 16) * 16;
+        const size_t ctl_bytes = ((sizeof(TrsvCtl) + 15) / 16) * 16;
         char* base = (char*)oisat_ws(h, 7, 16 + 2 * ctl_bytes);
         if (!base) return OISAT_ENOMEM;
         HIP_TRY(hipMemsetAsync(base, 0, 16, h->stream));      // triangular-solve time-out counter
