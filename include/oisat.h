@@ -232,8 +232,10 @@ int oisat_innovation(oisat_ctx* h, int dtype, const void* xb, const int64_t* cel
 
 /* The one O(m^3) kernel of the factorization, exposed for tests and microbenchmarks:
  * mode 0: C -= A B^T, mode 1: C = A B^T.  C: M x N (ldc), A: M x K (lda), B: N x K (ldb), row-major,
- * K-contiguous operands; M, N multiples of 128, K of 32; lower != 0 skips tiles above the diagonal
- * of a diagonal-anchored C.  fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32. */
+ * K-contiguous operands; M, N multiples of 128, K of 32; lower != 0: C is anchored on the diagonal and only its
+ * lower triangle is defined afterwards -- tiles strictly above the diagonal are skipped, at 128- or 64-row/column
+ * granularity depending on the launch size, so entries above the diagonal may or may not have been updated.
+ * fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32. */
 int oisat_gemm_nt(oisat_ctx* h, float* C, int64_t ldc, const float* A, int64_t lda, const float* B, int64_t ldb,
                   int64_t M, int64_t N, int64_t K, int mode, int lower);
 

@@ -10,17 +10,18 @@
 //     gemm_nt:  C[MxN] (-)= A[MxK] * B[NxK]^T      (both operands K-contiguous, "NT")
 // built on v_mfma_f32_32x32x2_f32 (exact fp32, 256 flop/clk/CU = 157 TFLOP/s peak):
 //   * 128x128 block tile, 4 waves as 2x2, each wave 64x64 = 2x2 MFMA tiles (64 accumulator VGPRs)
-//   * K in steps of 32 through a double-buffered LDS image [128][36] floats per operand: the
-//     4-float pad makes every ds_read_b128 fragment read bank-conflict-free (rows 36*r mod 64
-//     hit 16 distinct 4-bank slots per 16-lane group)
+//   * K in steps of 32 through a double-buffered LDS image [128][32] floats per operand, filled by LDS-DMA
+//     (global_load_lds_dwordx4: no staging registers, no ds_write) and XOR-swizzled at 16-byte granularity --
+//     chunk c of row r lives at chunk c ^ (r & 7) -- so that every ds_read_b128 fragment read is conflict-free
+//     without padding (a DMA instruction fills LDS linearly, padding is not expressible)
 //   * a lane reads k = 8s+4h..+3 as one ds_read_b128 and feeds 4 consecutive MFMAs; A and B use
 //     the same k permutation, so the product is unchanged
 //   * software pipeline, skewed across the barrier: the fragments of MFMA group s+1 are read from
 //     LDS while group s runs (two fragment register sets); the one barrier per K-tile sits before
 //     the LAST group, so the first fragments of tile t+1 are fetched behind 16 MFMAs instead of in
 //     front of an idle pipe (measured +7 %: 129 -> 138 TFLOP/s at 8192^3)
-//   * global->register prefetch of tile t+1 is issued at the top of tile t and parked in the other
-//     LDS buffer half-way through its MFMAs
+//   * the DMA of tile t+1 is issued at the top of tile t into the other buffer; each wave waits for its own
+//     pieces (vmcnt) only right before the barrier: three MFMA groups of cover
 //   * blockIdx -> tile map keeps each XCD (private 4 MiB L2) on a contiguous strip of tiles that
 //     share B rows
 // The 128x128 diagonal blocks are factored and inverted by one workgroup in LDS; the panel below
@@ -42,7 +43,7 @@ constexpr int LDSW = 36;         // padded LDS row stride in floats (144 B, 16-B
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(float* C, int64_t ldc, const float* A,
                                                           int64_t lda, const float* __restrict__ B, int64_t ldb, int ntm,
                                                           int ntn, int K, int mode, int lower, int ntiles_total) {
-    __shared__ __attribute__((aligned(16))) float lds[2][2][NB * LDSW];      // [buf][A|B][row*36+k]  = 73,728 B
+    __shared__ __attribute__((aligned(16))) float lds[2][2][NB * BK];        // [buf][A|B][row*32 + 4*(chunk ^ (row&7))] = 65,536 B
     // XCD-aware, bijective remap: blocks b, b+8, b+16.. share an XCD -> give each XCD a contiguous strip
     const int nwg = gridDim.x;
     const int orig = blockIdx.x;
@@ -80,55 +81,48 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(float* C, int64_t ldc, 
     }
     (void)ntiles_total;
     const int t = threadIdx.x;
-    const int lane = t & 63, wid = t >> 6;
+    const int lane = t & 63, wid = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wr = wid >> 1, wc = wid & 1;
     const float* Ag = A + (int64_t)ti * NB * lda;
     const float* Bg = B + (int64_t)tj * NB * ldb;
-    // staging: pass p covers rows p*32 + (t>>3), 16 bytes at k = (t&7)*4
-    const int srow = t >> 3, sk = (t & 7) * 4;
-    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;     // named registers (arrays behind lambdas went to scratch)
-    const float* Ap = Ag + (int64_t)srow * lda + sk;
-    const float* Bp = Bg + (int64_t)srow * ldb + sk;
-#define OISAT_GLOAD(k0)                                                              \
-    do {                                                                             \
-        ra0 = *reinterpret_cast<const float4*>(Ap + (k0));                           \
-        ra1 = *reinterpret_cast<const float4*>(Ap + 32 * lda + (k0));                \
-        ra2 = *reinterpret_cast<const float4*>(Ap + 64 * lda + (k0));                \
-        ra3 = *reinterpret_cast<const float4*>(Ap + 96 * lda + (k0));                \
-        rb0 = *reinterpret_cast<const float4*>(Bp + (k0));                           \
-        rb1 = *reinterpret_cast<const float4*>(Bp + 32 * ldb + (k0));                \
-        rb2 = *reinterpret_cast<const float4*>(Bp + 64 * ldb + (k0));                \
-        rb3 = *reinterpret_cast<const float4*>(Bp + 96 * ldb + (k0));                \
-    } while (0)
-#define OISAT_LSTORE(buf)                                                            \
-    do {                                                                             \
-        float* wa = &lds[buf][0][srow * LDSW + sk];                                  \
-        float* wb = &lds[buf][1][srow * LDSW + sk];                                  \
-        *reinterpret_cast<float4*>(wa) = ra0;                                        \
-        *reinterpret_cast<float4*>(wa + 32 * LDSW) = ra1;                            \
-        *reinterpret_cast<float4*>(wa + 64 * LDSW) = ra2;                            \
-        *reinterpret_cast<float4*>(wa + 96 * LDSW) = ra3;                            \
-        *reinterpret_cast<float4*>(wb) = rb0;                                        \
-        *reinterpret_cast<float4*>(wb + 32 * LDSW) = rb1;                            \
-        *reinterpret_cast<float4*>(wb + 64 * LDSW) = rb2;                            \
-        *reinterpret_cast<float4*>(wb + 96 * LDSW) = rb3;                            \
+    // LDS-DMA (global_load_lds_dwordx4): wave `wid` brings rows wid*32 + 8i .. +7 (i = 0..3) of each operand, one KiB
+    // per instruction, straight into LDS -- no staging registers, no ds_write, and the wave only waits for its pieces
+    // right before the barrier.  A DMA instruction fills LDS linearly (lane l -> 16 bytes at 16 l), so the image cannot
+    // be padded; it is XOR-swizzled instead: lane l lands at physical chunk (l&7) of row (l>>3) and therefore fetches
+    // the LOGICAL chunk (l&7) ^ (row&7) of that row from global memory (still one 128-byte segment per row).
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const int rl = lane >> 3, lc = (lane & 7) ^ rl;
+    const float* Ad = Ag + (int64_t)(wid * 32 + rl) * lda + 4 * lc;
+    const float* Bd = Bg + (int64_t)(wid * 32 + rl) * ldb + 4 * lc;
+#define OISAT_DMA(buf, k0)                                                                                         \
+    do {                                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                            \
+            __builtin_amdgcn_global_load_lds((gptr_t)(Ad + (int64_t)(8 * i) * lda + (k0)),                         \
+                                             (lptr_t)&lds[buf][0][(wid * 32 + 8 * i) * BK], 16, 0, 0);             \
+            __builtin_amdgcn_global_load_lds((gptr_t)(Bd + (int64_t)(8 * i) * ldb + (k0)),                         \
+                                             (lptr_t)&lds[buf][1][(wid * 32 + 8 * i) * BK], 16, 0, 0);             \
+        }                                                                                                          \
     } while (0)
     f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
 
     const int nkt = K / BK;
-    OISAT_GLOAD(0);
-    OISAT_LSTORE(0);
+    OISAT_DMA(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int frow = lane & 31, fh = lane >> 5;
-    const int aoff = (wr * 64 + frow) * LDSW + 4 * fh, boff = (wc * 64 + frow) * LDSW + 4 * fh;
+    // a lane's fragment of K-group s is logical chunk 2s+fh of its row: physical chunk (2s+fh) ^ (row&7).  Any 8 consecutive
+    // rows hold one logical chunk in 8 different physical chunks = all 32 banks once: conflict-free ds_read_b128.
+    const int sw = frow & 7;
+    const int arow = (wr * 64 + frow) * BK, brow = (wc * 64 + frow) * BK;
     // fragment registers, two sets: the operands of MFMA group s+1 are read from LDS while group s runs
     float4 fa0, fa1, fb0, fb1, ga0, ga1, gb0, gb1;
 #define OISAT_FRAG(A0, A1, B0, B1, buf, s)                                                      \
     do {                                                                                        \
-        A0 = *reinterpret_cast<const float4*>(&lds[buf][0][aoff + 8 * (s)]);                    \
-        A1 = *reinterpret_cast<const float4*>(&lds[buf][0][aoff + 32 * LDSW + 8 * (s)]);        \
-        B0 = *reinterpret_cast<const float4*>(&lds[buf][1][boff + 8 * (s)]);                    \
-        B1 = *reinterpret_cast<const float4*>(&lds[buf][1][boff + 32 * LDSW + 8 * (s)]);        \
+        A0 = *reinterpret_cast<const float4*>(&lds[buf][0][arow + 4 * ((2 * (s) + fh) ^ sw)]);            \
+        A1 = *reinterpret_cast<const float4*>(&lds[buf][0][arow + 32 * BK + 4 * ((2 * (s) + fh) ^ sw)]);  \
+        B0 = *reinterpret_cast<const float4*>(&lds[buf][1][brow + 4 * ((2 * (s) + fh) ^ sw)]);            \
+        B1 = *reinterpret_cast<const float4*>(&lds[buf][1][brow + 32 * BK + 4 * ((2 * (s) + fh) ^ sw)]);  \
     } while (0)
 #define OISAT_MFMA4(A0, A1, B0, B1, c)                                                          \
     acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.c, B0.c, acc00, 0, 0, 0);                   \
@@ -141,15 +135,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(float* C, int64_t ldc, 
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
         const bool more = kt + 1 < nkt;
-        if (more) OISAT_GLOAD((kt + 1) * BK);
+        if (more) OISAT_DMA(cur ^ 1, (kt + 1) * BK);            // the other buffer is free since the last barrier
         OISAT_FRAG(ga0, ga1, gb0, gb1, cur, 1);
         OISAT_MFMA16(fa0, fa1, fb0, fb1)                       // s = 0
         OISAT_FRAG(fa0, fa1, fb0, fb1, cur, 2);
         OISAT_MFMA16(ga0, ga1, gb0, gb1)                       // s = 1
-        if (more) OISAT_LSTORE(cur ^ 1);                        // other buffer is free since the last barrier
         OISAT_FRAG(ga0, ga1, gb0, gb1, cur, 3);
         OISAT_MFMA16(fa0, fa1, fb0, fb1)                       // s = 2
-        __syncthreads();                                        // tile kt+1 visible; every read of tile kt has been issued
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's DMA pieces of tile kt+1 have landed ...
+        __syncthreads();                                        // ... and so have everyone else's; every read of tile kt has been issued
         if (more) OISAT_FRAG(fa0, fa1, fb0, fb1, cur ^ 1, 0);   // first operands of the next tile, behind the last MFMA group
         OISAT_MFMA16(ga0, ga1, gb0, gb1)                       // s = 3
     }
