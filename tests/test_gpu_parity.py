@@ -1139,6 +1139,29 @@ def test_c_abi_rejects_bad_arguments(ctx):
     other.close()
 
 
+def test_integration_md_stub_works_as_written(ctx, golden, tmp_path, monkeypatch):
+    """INTEGRATION.md section B shows the ctypes stub a maintainer of the reference would add; run that very code block
+    against the library and compare with the reference's golden OI output (forced knee index)."""
+    import importlib.util
+    import re
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")).read()
+    m = re.search(r"```python\n(# oisatgmi/_oisat_hip\.py.*?)```", text, re.S)
+    assert m, "stub code block not found in INTEGRATION.md"
+    stub = tmp_path / "_oisat_hip_stub.py"
+    stub.write_text(m.group(1))
+    monkeypatch.setenv("OISAT_LIB", _hip.library_path())
+    spec = importlib.util.spec_from_file_location("_oisat_hip_stub", str(stub))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    g = golden("oi_72x144.npz")
+    Xa, Y, Sa, So = _oi_inputs(g)
+    scales = orc.scaling_factors(True)
+    Yc = Y.copy()
+    Xb, AK, inc, err = mod.oi_hip(Xa, Yc, Sa, So, scales, lambda x, y: 37)
+    _check_pack(g, "on37", (Xb, AK, inc, err), RT64)
+    assert not (Yc[~np.isnan(Yc)] < 0).any()
+
+
 def test_plain_c_client_runs_on_the_gpu(ctx, tmp_path):
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
