@@ -179,6 +179,39 @@ def test_fused_device_knee_matches_host_path(ctx, golden):
     assert len(seen) > 3
 
 
+def test_fused_oi_is_hipgraph_capturable(ctx, golden):
+    """include/oisat.h says oisat_oi_fused makes no host round trip: capture it in a hipGraph (through torch's stream
+    capture on the stream the handle launches on), replay, and compare with the direct call."""
+    import torch
+    from oisatgmi.optimal_interpolation import DiagOI
+    g = golden("oi_72x144.npz")
+    Xa, Y, Sa, So = _oi_inputs(g)
+    own = torch.cuda.Stream()
+    ctx.set_stream(own.cuda_stream)
+    try:
+        d = DiagOI(Xa.size, dtype=np.float64, ctx=ctx)
+        d.load(Xa, Y.copy(), Sa, So)
+        d.run_fused(True)                                   # warm: uploads the scaling table once
+        ctx.sync()
+        idx0, curve0 = d.fused_result()
+        direct = [a.copy() for a in d.download(Xa.shape)]
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=own):
+            ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+            d.run_fused(True)
+        ctx.set_stream(own.cuda_stream)
+        d.load(Xa, Y.copy(), Sa, So)                        # fresh inputs in the same buffers, then replay only
+        graph.replay()
+        torch.cuda.synchronize()
+        idx1, curve1 = d.fused_result()
+        assert idx1 == idx0
+        np.testing.assert_array_equal(curve1, curve0)
+        for a, b in zip(d.download(Xa.shape), direct):
+            np.testing.assert_array_equal(a, b)
+    finally:
+        ctx.set_stream(None)
+
+
 def test_oi_edge_shapes(ctx):
     # 1 cell, odd sizes, all-NaN observations
     for shape in ((1, 1), (3, 5), (1, 129), (257, 3)):
