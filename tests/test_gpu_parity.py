@@ -736,6 +736,25 @@ def test_dense_analysis_against_oracle(ctx, ny, nx, m, L):
         assert np.abs(info["z"] - ref["z"]).max() <= ztol * np.abs(ref["z"]).max()
 
 
+def test_dense_analysis_is_bitwise_reproducible(ctx):
+    """Same inputs, same bits: no atomics on the data path, fixed reduction orders, the pipelined triangular solves
+    hand values over but never reorder sums.  Two runs of one plan and a run of a second plan must agree exactly."""
+    p, cell = _dense_case(120, 240, 3000, 77, swaths=True)
+    y = np.where(p.obs_y < 0, 0, p.obs_y)
+    outs = []
+    for rep in range(2):
+        plan = dense.DenseAnalysis(p.lat, p.lon, max_obs=int(y.size), dtype=np.float32)
+        plan.load_background(p.Xa, p.Sa)
+        plan.load_obs(p.obs_lat, p.obs_lon, cell, y, p.obs_var)
+        for _ in range(2):
+            plan.run(350.0, refine=2)
+            xa, inc = plan.download()
+            outs.append((xa.copy(), inc.copy(), plan.download_z().copy()))
+    for o in outs[1:]:
+        for a, b in zip(o, outs[0]):
+            np.testing.assert_array_equal(a, b)
+
+
 def test_dense_edge_sizes(ctx):
     """Observation counts around the 128-row blocking of the factorization, down to one and to none."""
     for m in (0, 1, 2, 5, 127, 128, 129, 257):
