@@ -19,26 +19,35 @@ import numpy as np
 def shard_units(units, world: int, rank: int, weights=None):
     """Static partition of work units (month x species x tile) over ranks.
     Without weights: round-robin.  With weights (e.g. obs-count^3 of each unit): longest-processing-
-    time-first greedy, deterministic, identical on every rank (no communication needed)."""
+    time-first greedy, deterministic, identical on every rank (no communication needed).  The shard
+    comes back in LPT order -- heaviest unit first -- which is also the order to run it in: the big
+    factorizations start while every lane is still busy and the small ones fill the tail."""
     units = list(units)
+    return [units[i] for i in partition_units(len(units), world, weights)[rank]]
+
+
+def partition_units(n_units: int, world: int, weights=None):
+    """``[unit indices of rank 0, of rank 1, ...]`` -- the whole static partition (every rank can
+    compute it: rank 0 needs it to unpack the gather).  Each list is in run order."""
     if weights is None:
-        return units[rank::world]
-    order = sorted(range(len(units)), key=lambda i: (-float(weights[i]), i))
+        return [list(range(r, n_units, world)) for r in range(world)]
+    if len(weights) != n_units:
+        raise ValueError(f"{len(weights)} weights for {n_units} units")
+    order = sorted(range(n_units), key=lambda i: (-float(weights[i]), i))
     load = [0.0] * world
-    mine = []
+    parts = [[] for _ in range(world)]
     for i in order:
         r = min(range(world), key=lambda q: (load[q], q))
         load[r] += float(weights[i])
-        if r == rank:
-            mine.append(i)
-    return [units[i] for i in sorted(mine)]
+        parts[r].append(i)
+    return parts
 
 
 def owner_of(n_units: int, world: int, weights=None):
     """rank that owns each unit under ``shard_units`` (for the gather bookkeeping on rank 0)."""
     owner = [None] * n_units
-    for r in range(world):
-        for u in shard_units(range(n_units), world, r, weights):
+    for r, part in enumerate(partition_units(n_units, world, weights)):
+        for u in part:
             owner[u] = r
     return owner
 
@@ -78,15 +87,14 @@ def broadcast_grid(lat, lon, shape, local_rank=None):
 
 
 def gather_to_root(tensor, dst=0):
-    """Every rank contributes one equally-shaped tensor; rank ``dst`` gets the list (rank order)."""
+    """Every rank contributes one equally-shaped tensor; rank ``dst`` -- and only it -- receives them
+    (list in rank order, ``None`` elsewhere).  ``dist.gather`` on both backends: over RCCL it is a
+    group of point-to-point sends into ``dst``, so the other ranks receive nothing (an all-gather
+    would move world x the bytes the analysis needs)."""
     import torch
     dist = _dist()
     world, rank = dist.get_world_size(), dist.get_rank()
-    if dist.get_backend() == "nccl":
-        # RCCL: one all_gather into a preallocated slab is the cheapest portable form at MB sizes
-        slab = torch.empty((world,) + tuple(tensor.shape), dtype=tensor.dtype, device=tensor.device)
-        dist.all_gather_into_tensor(slab, tensor.contiguous())
-        return [slab[r] for r in range(world)] if rank == dst else None
+    tensor = tensor.contiguous()
     lst = [torch.empty_like(tensor) for _ in range(world)] if rank == dst else None
     dist.gather(tensor, gather_list=lst, dst=dst)
     return lst
@@ -111,43 +119,59 @@ class FieldGather:
         typestr = "<f4" if item == 4 else "<f8"
         view = _DevView(plan.fields.at(plan.n * item), 2 * plan.n, typestr)
         self.send = torch.as_tensor(view, device=torch.device("cuda", local_rank))
-        self.slab = torch.empty((world, 2 * plan.n), dtype=self.send.dtype, device=self.send.device)
+        # only the root holds the receive slab
+        self.slab = torch.empty((world, 2 * plan.n), dtype=self.send.dtype, device=self.send.device) if rank == 0 else None
         self.shape = plan.shape
 
     def run(self):
+        """xa|inc of this rank's month -> rank 0 (a gather, not an all-gather: nobody else needs them)."""
         dist = _dist()
-        if dist.get_backend() == "nccl":
-            dist.all_gather_into_tensor(self.slab, self.send)       # RCCL, device to device over xGMI
-        else:                                                       # rehearsal backends (gloo): list form
-            parts = [self.slab[r] for r in range(self.world)]
-            dist.all_gather(parts, self.send)
-        return self.slab
+        parts = [self.slab[r] for r in range(self.world)] if self.rank == 0 else None
+        dist.gather(self.send, gather_list=parts, dst=0)
+        return self.slab if self.rank == 0 else None
 
     def fields(self):
-        """rank-major (world, 2, ny, nx) host array of (xa, inc)."""
+        """rank-major (world, 2, ny, nx) host array of (xa, inc); rank 0 only."""
         return self.slab.cpu().numpy().reshape((self.world, 2) + tuple(self.shape))
 
 
-def analyse_units(units, analyse, weights=None, result_shape=None, dtype=None, device="cpu"):
-    """Run ``analyse(unit) -> tensor(result_shape)`` for this rank's shard and collect every unit's
-    result on rank 0 in unit order.  Ranks with fewer units contribute zero slabs on the last rounds
-    (a collective needs every rank).  Returns list-of-tensors on rank 0, None elsewhere."""
+def analyse_units(units, analyse, weights=None, result_shape=None, dtype=None, device="cpu", finish=None):
+    """Run ``analyse(unit) -> tensor`` for this rank's shard and collect every unit's result on rank 0
+    in unit order.  Returns list-of-tensors on rank 0, None elsewhere.
+
+    There is NO collective inside the unit loop: a rank runs its whole shard, heaviest unit first, at
+    its own pace, and the results travel in ONE gather at the end -- so the wall time is the most
+    loaded rank's total, not the sum over rounds of the slowest unit of each round (units differ by
+    ~90x in cost when they are weighted by obs^3).  ``analyse`` may merely enqueue device work;
+    ``finish()`` (optional) is called once after the loop to wait for it before the gather.
+    ``result_shape``: one shape for every unit, or a callable ``unit -> shape``."""
     import torch
     dist = _dist()
     world, rank = dist.get_world_size(), dist.get_rank()
     units = list(units)
-    mine = shard_units(range(len(units)), world, rank, weights)
-    per_rank = [shard_units(range(len(units)), world, r, weights) for r in range(world)]
-    rounds = max(len(p) for p in per_rank)
+    parts = partition_units(len(units), world, weights)
+    shape_of = result_shape if callable(result_shape) else (lambda u: tuple(result_shape))
+    numel = [int(np.prod(shape_of(u))) for u in units]
+    cap = max(sum(numel[i] for i in part) for part in parts)          # every rank sends a slab of this size
+    got_local = [analyse(units[i]) for i in parts[rank]]
+    if finish is not None:
+        finish()
+    if dtype is None:
+        dtype = got_local[0].dtype if got_local else torch.float32
+    slab = torch.zeros(max(cap, 1), dtype=dtype, device=device)
+    off = 0
+    for i, t in zip(parts[rank], got_local):
+        if int(t.numel()) != numel[i]:
+            raise ValueError(f"unit {units[i]!r}: analyse returned {tuple(t.shape)}, expected {shape_of(units[i])}")
+        slab[off:off + numel[i]] = t.reshape(-1).to(dtype)
+        off += numel[i]
+    got = gather_to_root(slab, dst=0)                                  # the one collective of the data path
+    if rank != 0:
+        return None
     results = [None] * len(units)
-    for k in range(rounds):
-        if k < len(mine):
-            t = analyse(units[mine[k]])
-        else:
-            t = torch.zeros(result_shape, dtype=dtype, device=device)
-        got = gather_to_root(t, dst=0)
-        if rank == 0:
-            for r in range(world):
-                if k < len(per_rank[r]):
-                    results[per_rank[r][k]] = got[r].clone()
-    return results if rank == 0 else None
+    for r, part in enumerate(parts):
+        off = 0
+        for i in part:
+            results[i] = got[r][off:off + numel[i]].reshape(shape_of(units[i])).clone()
+            off += numel[i]
+    return results

@@ -82,6 +82,14 @@ def _worker(rank, world, port, q):
                 ok = ok and np.array_equal(res[i].numpy(), np.stack([lat * month, lon + month]))
         else:
             ok = ok and res is None
+        # ragged results (tiles of different sizes) with weights: one gather, unpacked per unit on rank 0
+        shapes = {u: (2, u + 1, 3) for u in range(5)}
+        rag = parallel.analyse_units(range(5), lambda u: torch.full(shapes[u], float(u)), weights=[5, 1, 4, 2, 3],
+                                     result_shape=lambda u: shapes[u], dtype=torch.float64)
+        if rank == 0:
+            ok = ok and all(tuple(rag[u].shape) == shapes[u] and bool((rag[u] == float(u)).all()) for u in range(5))
+        else:
+            ok = ok and rag is None
         got = parallel.gather_to_root(torch.full((3,), float(rank)))
         if rank == 0:
             ok = ok and [float(t[0]) for t in got] == [0.0, 1.0]
@@ -102,3 +110,65 @@ def test_two_ranks_over_gloo():
         assert p.exitcode == 0
     got = dict(q.get(timeout=10) for _ in range(2))
     assert got == {0: True, 1: True}
+
+
+def _sched_worker(rank, world, port, q):
+    import time
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # one heavy unit and eight light ones: LPT gives rank 0 the heavy one and rank 1 the eight light ones
+        # (load 8 | 8).  A collective per round would cost max(8,1) + 7 x 1 = 15 units of time; running the
+        # shard through and gathering once costs 8.
+        weights = [1, 1, 8, 1, 1, 1, 1, 1, 1]
+        unit_s = 0.06
+        ran = []
+
+        def analyse(u):
+            ran.append(u)
+            time.sleep(unit_s * weights[u])
+            return torch.full((2, 3), float(u))
+
+        dist.barrier()
+        t0 = time.perf_counter()
+        res = parallel.analyse_units(range(len(weights)), analyse, weights=weights, result_shape=(2, 3), dtype=torch.float32)
+        dist.barrier()
+        wall = time.perf_counter() - t0
+        ok = True
+        if rank == 0:
+            ok = ok and ran == [2]
+            ok = ok and all(float(res[u][0, 0]) == float(u) and tuple(res[u].shape) == (2, 3) for u in range(len(weights)))
+        else:
+            ok = ok and sorted(ran) == [0, 1, 3, 4, 5, 6, 7, 8] and res is None
+        q.put((rank, bool(ok), wall, unit_s))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_no_collective_inside_the_unit_loop():
+    """the wall time of a sharded run must be the most loaded rank's total (max_r sum_k cost), not
+    sum_k max_r cost -- i.e. ranks must not be lock-stepped by a per-round gather."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sched_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    got = [q.get(timeout=10) for _ in range(2)]
+    assert all(g[1] for g in got), got
+    unit_s = got[0][3]
+    wall = max(g[2] for g in got)
+    assert wall < 8 * unit_s * 1.4, (wall, 8 * unit_s)          # lock-stepped rounds would take 15 * unit_s
+    assert wall >= 8 * unit_s * 0.98
+
+
+def test_shards_come_back_heaviest_first_and_ragged_results_gather():
+    w = [3.0, 9.0, 1.0, 27.0, 2.0]
+    parts = parallel.partition_units(5, 2, w)
+    assert parts == [[3], [1, 0, 4, 2]]
+    assert parallel.shard_units("abcde", 2, 1, w) == ["b", "a", "e", "c"]
+    assert parallel.partition_units(5, 2) == [[0, 2, 4], [1, 3]]
