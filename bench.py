@@ -16,6 +16,8 @@ timed as a secondary leg in the same run and is the size the parity tests valida
 With N > 1 every rank analyses its own month (months are independent work units, as in the
 reference's one-job-per-month launch, run/job_submitter_sbatch.py:45-68): the shared grid is
 broadcast once from rank 0 and the analysis fields are gathered every step over RCCL -- weak scaling.
+Every run, at every N, additionally times the FIXED 12-month (month x tile) workload of configs[3]
+(`config4_strong`): seconds(1) / seconds(N) is the strong-scaling curve.
 
 Prints ONE JSON line (rank 0).  Extra legs, N = 1 only: per-kernel HIP-event timing on the launch
 stream for the roofline object, the element-wise (reference-parity) OI on the same grid, and a
@@ -61,6 +63,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-config4", action="store_true", help="skip the fixed-workload strong-scaling leg (12 months x tiles)")
+    ap.add_argument("--c4-months", type=int, default=12)
+    ap.add_argument("--c4-passes", type=int, default=2)
     ap.add_argument("--backend", default="nccl", help="process-group backend; gloo only to rehearse N>1 on a 1-GPU box")
     ap.add_argument("--rehearse-on-device0", action="store_true", help="every rank uses GPU 0 (rehearsal only)")
     return ap.parse_args()
@@ -263,6 +268,95 @@ def cpu_baseline(workload):
                       f"its Cholesky cost grows as obs^3, so the CPU rate on the full step is far lower than this"}
 
 
+def config4_leg(ctx, args, world, rank, local, lat2, lon2, sync, barrier):
+    """BASELINE configs[3], STRONG scaling: a FIXED workload -- `c4_months` synthetic 720x1440 months of 10^5 swath
+    observations, each cut into 30 deg x 30 deg tiles with a 3 L halo (localised block-B) -- split into (month x tile)
+    units, sharded over the ranks by obs^3-weighted LPT (parallel.partition_units), every rank running its whole shard
+    on the lanes of one pool with no collective and no host synchronisation inside, and ONE gather of all `xa | inc`
+    tiles to rank 0 at the end.  The same leg runs at every --gpus N (N = 1 included), so seconds(1) / seconds(N) is the
+    strong-scaling curve (reference: one scheduler job per month, run/job_submitter_sbatch.py:45-68; with months as the
+    only unit 8 GPUs cap at 12/2 = 6.0x, hence the finer unit)."""
+    import torch
+    import torch.distributed as dist
+    from oisatgmi import synthetic as syn, dense, parallel
+    ny, nx, nobs, L, swaths, refine = WORKLOADS[DEFAULT]
+    halo = 3.0 * L
+    cases, units, weights, cells = {}, [], [], []
+    for mth in range(args.c4_months):                     # seeded: every rank derives the same months, nothing to broadcast
+        p = syn.point_obs_case(ny, nx, nobs, 4000 + mth, swaths=swaths)
+        cases[mth] = p
+        for ti, t in enumerate(dense.tile_partition(lat2, lon2, p.obs_lat, p.obs_lon, 30.0, halo)):
+            if t["obs"].size:
+                units.append((mth, ti))
+                weights.append(float(t["obs"].size) ** 3)
+                cells.append((t["rows"][1] - t["rows"][0]) * (t["cols"][1] - t["cols"][0]))
+    parts = parallel.partition_units(len(units), world, weights)
+    loads = [sum(weights[i] for i in part) for part in parts]
+    cap = max(sum(2 * cells[i] for i in part) for part in parts)      # slab elements every rank sends
+    batch = dense.MonthTileBatch(lat2, lon2, 30.0, halo, np.float32, ctx=ctx, streams=12)
+    for mth in range(args.c4_months):
+        only = [units[i][1] for i in parts[rank] if units[i][0] == mth]
+        if only:
+            p = cases[mth]
+            batch.add_month(mth, p.Xa, p.Sa, p.obs_lat, p.obs_lon, p.obs_y, p.obs_var, only=only)
+    batch.build(min_slab_elems=cap)
+    assert sorted((k, ti) for k, ti, _ in batch.units) == sorted(units[i] for i in parts[rank])
+    del cases
+    send = torch.as_tensor(parallel._DevView(batch.slab.ptr, cap, "<f4"), device=torch.device("cuda", local))
+
+    def one_pass():
+        batch.run(L, refine=refine, wait=False)           # enqueue the whole shard, heaviest unit first
+        batch.pool.check("config 4 shard")                # wait for the lanes; any failed solve raises
+        if world > 1:
+            return parallel.gather_to_root(send)           # the one collective of the data path
+        return [send]
+
+    batch.run(L, refine=refine, check_pd=True)             # checked pass, untimed
+    one_pass()                                             # warm-up (RCCL connections)
+    sync()
+    if barrier:
+        barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.c4_passes):
+        got = one_pass()
+    sync()
+    t_own = time.perf_counter() - t0                       # this rank's own time, before waiting for the others
+    if barrier:
+        barrier()
+    sync()
+    el = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([el, t_own], device="cuda", dtype=torch.float64)
+        tmax = tt.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tmin = tt.clone()
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        el, own_max, own_min = float(tmax[0]), float(tmax[1]), float(tmin[1])
+    else:
+        own_max = own_min = t_own
+    out = None
+    if rank == 0:
+        # every unit's tile arrived: finite, and the increment is not identically zero
+        ok = True
+        for r, part in enumerate(parts):
+            host = got[r].cpu().numpy()
+            used = sum(2 * cells[i] for i in part)
+            ok = ok and bool(np.isfinite(host[:used]).all()) and bool(np.any(host[:used] != 0))
+        sec = el / args.c4_passes
+        flops = sum(dense.DenseAnalysis.flops(round(w ** (1.0 / 3.0))) for w in weights)
+        out = {"workload": f"{args.c4_months} months x (720x1440, 1e5 swath obs), localised block-B: 30 deg tiles, halo {halo:.0f} km",
+               "scaling": "strong", "n_gpus": world, "units": len(units), "seconds": sec,
+               "value": args.c4_months * ny * nx / sec, "unit": "grid-cells/s",
+               "solve_tflops_end_to_end": flops / sec / 1e12,
+               "max_rank_load_over_mean": max(loads) / (sum(loads) / world),
+               "speedup_bound_from_load_balance": sum(loads) / max(loads),
+               "rank_seconds_min_max": [own_min / args.c4_passes, own_max / args.c4_passes],
+               "units_per_rank": [len(part) for part in parts], "all_tiles_arrived_finite": ok,
+               "gather": "one dist.gather of %.1f MB per rank to rank 0 per pass" % (4e-6 * cap)}
+    batch.close()
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -333,7 +427,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload, "species": args.species, "grid": [ny, nx], "obs_per_month": m, "corr_length_km": L,
                        "refine": refine, "months_per_step": world,
-                       "parallelism": "one month per GPU; RCCL broadcast of the grid, all-gather of fields"},
+                       "parallelism": "one month per GPU; RCCL broadcast of the grid, gather of the fields to rank 0"},
             "solve_tflops_end_to_end": world * flops / (elapsed / args.steps) / 1e12,
             "refinement_residuals": resid,
         }
@@ -377,6 +471,13 @@ def main():
             out["regrid"] = regrid_leg(ctx, sync)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)
+    if not args.no_config4:
+        del gather
+        if world > 1:
+            del plan                                       # its 40 GB factor goes back before the tile lanes allocate theirs
+        c4 = config4_leg(ctx, args, world, rank, local, lat2, lon2, sync, barrier)
+        if rank == 0:
+            out["config4_strong"] = c4
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

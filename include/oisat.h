@@ -14,8 +14,10 @@
  *     oisat_last_error() gives the thread-local message.
  *   - "dev" pointers are HIP device pointers owned by the caller (e.g. torch tensors'
  *     data_ptr(), or memory from oisat_dmalloc).  Kernels are enqueued on the handle's stream
- *     (oisat_set_stream) and are asynchronous unless stated; nothing here calls hipMalloc /
- *     hipFree / hipDeviceSynchronize on a compute path except where a host result is returned.
+ *     (oisat_set_stream) and are asynchronous unless stated.  Internal workspaces are grow-only:
+ *     a compute call allocates only when it meets a size larger than any before it on this handle
+ *     (oisat_dense_reserve pre-sizes the dense path so that this never happens inside a timed or
+ *     repeated region); nothing synchronises the device except where a host result is returned.
  *   - dtype: OISAT_F32 (0) or OISAT_F64 (1) selects the field element type; arithmetic is done
  *     in that type with the reference's operation order (no fast-math, no FMA contraction), and
  *     reductions always accumulate in double.
@@ -285,6 +287,21 @@ int oisat_posterior_error(oisat_ctx* h, const float* L, int64_t m, int64_t ld, c
  * (the dense counterpart of AK = 1 - Sb/(Sa*reg), optimal_interpolation.py:31).  ak_out: dev double[m]. */
 int oisat_gain_diag(oisat_ctx* h, const float* L, int64_t m, int64_t ld, const double* ovar, int64_t chunk_rows,
                     double* ak_out);
+
+/* Status of the dense solves enqueued on this handle since the last call with clear != 0 (synchronises the stream; one
+ * 20-byte read-back).  oisat_potrf / oisat_gain_solve only report failures when given info_host / resid_host; an
+ * unchecked (fully asynchronous) run records them here instead:
+ *   first_notpd_col  1-based column of the first non-positive pivot of any factorization (0 = none),
+ *   n_notpd_blocks   number of diagonal blocks that met one,
+ *   trsv_timeouts    triangular-solve workgroups that gave up waiting for a predecessor (their part of z is a NaN
+ *                    fill pattern).
+ * Any of the three may be NULL.  A caller must see three zeros before it trusts z / the analysis fields. */
+int oisat_solve_status(oisat_ctx* h, int* first_notpd_col, int* n_notpd_blocks, int* trsv_timeouts, int clear);
+
+/* Pre-size every internal workspace of the dense path for analyses of up to max_obs observations (and, if
+ * diag_chunk_rows > 0, for oisat_posterior_error / oisat_gain_diag with that chunk size), so that no later
+ * oisat_potrf / oisat_gain_solve / ... call on this handle allocates or frees device memory. */
+int oisat_dense_reserve(oisat_ctx* h, int64_t max_obs, int64_t diag_chunk_rows);
 
 #ifdef __cplusplus
 }

@@ -363,7 +363,11 @@ __device__ __forceinline__ void diag16_factor_invert(float* a, int j0, float* di
             x[c] -= l * x[k];
         }
     }
-    if (bad && lane == 0) atomicCAS(info, 0, col0 + bad);
+    if (bad && lane == 0) {               // info[0]: this factorization; info[1], info[2]: sticky (first column, count)
+        atomicCAS(info, 0, col0 + bad);  //          until oisat_solve_status clears them
+        atomicCAS(info + 1, 0, col0 + bad);
+        atomicAdd(info + 2, 1);
+    }
 #pragma unroll
     for (int c = 0; c < 16; ++c)
         if (lane < 16) a[(j0 + r) * LDA + j0 + c] = (c <= r) ? d[c] : 0.f;
@@ -875,12 +879,29 @@ int potrf_lookahead(oisat_ctx* h, float* S, int64_t ld, int64_t nb, float* tinv,
     return OISAT_OK;
 }
 
+// Status words of the dense solve, zeroed when first allocated and from then on only by oisat_solve_status(clear):
+//   slot 4: int info[4]   = { first non-positive pivot column of the CURRENT factorization (reset by oisat_potrf),
+//                             first such column since the last clear, number of failing diagonal blocks since then, - }
+//   slot 7: [unsigned err_total (16 B): triangular-solve workgroups that gave up waiting, since the last clear
+//            | control block of sweep 0 | control block of sweep 1]
+constexpr size_t kCtlBytes = ((sizeof(TrsvCtl) + 15) / 16) * 16;
+int status_ws(oisat_ctx* h, int** info_dev, char** trsv_base) {
+    const bool fresh4 = h->ws[4] == nullptr, fresh7 = h->ws[7] == nullptr;
+    int* info = (int*)oisat_ws(h, 4, 256);
+    char* base = (char*)oisat_ws(h, 7, 16 + 2 * kCtlBytes);
+    if (!info || !base) return OISAT_ENOMEM;
+    if (fresh4) HIP_TRY(hipMemsetAsync(info, 0, 256, h->stream));
+    if (fresh7) HIP_TRY(hipMemsetAsync(base, 0, 16 + 2 * kCtlBytes, h->stream));
+    if (info_dev) *info_dev = info;
+    if (trsv_base) *trsv_base = base;
+    return OISAT_OK;
+}
+
 int trsv_solve(oisat_ctx* h, const ChFactor& f, double* rhs_pad /* mp, overwritten with the solution */, double* tmp) {
     const int nb = (int)(f.mp / NB);
-    // slot 7: [err_total (16 B, cleared by oisat_potrf) | control block of sweep 0 | control block of sweep 1]
-    const size_t ctl_bytes = ((sizeof(TrsvCtl) + 15) / 16) * 16;
-    char* base = (char*)oisat_ws(h, 7, 16 + 2 * ctl_bytes);
-    if (!base) return OISAT_ENOMEM;
+    const size_t ctl_bytes = kCtlBytes;
+    char* base = nullptr;
+    if (int rc = status_ws(h, nullptr, &base)) return rc;
     unsigned* err_total = (unsigned*)base;
     char* ctl = base + 16;
     HIP_TRY(hipMemsetAsync(ctl, 0, 2 * ctl_bytes, h->stream));
@@ -930,8 +951,9 @@ extern "C" int oisat_potrf(oisat_ctx* h, float* S, int64_t m, int64_t ld, int* i
     ARG_CHECK(ld >= mp && (ld % 4) == 0 && ((uintptr_t)S % 16) == 0);
     const int64_t mpb = mp / NB;
     float* tinv = (float*)oisat_ws(h, 3, sizeof(float) * mpb * NB * NB);
-    int* info_dev = (int*)oisat_ws(h, 4, 256);
-    if (!tinv || !info_dev) return OISAT_ENOMEM;
+    int* info_dev = nullptr;
+    if (!tinv) return OISAT_ENOMEM;
+    if (int rc = status_ws(h, &info_dev, nullptr)) return rc;
     // per-function attributes, set once per process (handles may be driven from different host threads)
     static const hipError_t attr_rc = []() {
         hipError_t e = hipFuncSetAttribute((const void*)potrf_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -945,13 +967,7 @@ extern "C" int oisat_potrf(oisat_ctx* h, float* S, int64_t m, int64_t ld, int* i
         return e;
     }();
     HIP_TRY(attr_rc);
-    HIP_TRY(hipMemsetAsync(info_dev, 0, sizeof(int), h->stream));
-    {
-        const size_t ctl_bytes = ((sizeof(TrsvCtl) + 15) / 16) * 16;
-        char* base = (char*)oisat_ws(h, 7, 16 + 2 * ctl_bytes);
-        if (!base) return OISAT_ENOMEM;
-        HIP_TRY(hipMemsetAsync(base, 0, 16, h->stream));      // triangular-solve time-out counter
-    }
+    HIP_TRY(hipMemsetAsync(info_dev, 0, sizeof(int), h->stream));      // info[0] only: the sticky words survive
     if (mp > m) {
         OISAT_LAUNCH(h, "pad_identity", pad_identity_kernel, dim3(stream_grid((mp - m) * mp, 256)), dim3(256), 0, S, ld, m, mp);
     }
@@ -1111,5 +1127,42 @@ extern "C" int oisat_gain_diag(oisat_ctx* h, const float* L, int64_t m, int64_t 
         OISAT_LAUNCH(h, "gain_diag", gain_diag_kernel, dim3((unsigned)cdiv(live, 256)), dim3(256), 0, ovar, a0, live, m,
                      (const double*)ss, ak_out);
     }
+    return OISAT_OK;
+}
+
+extern "C" int oisat_solve_status(oisat_ctx* h, int* first_notpd_col, int* n_notpd_blocks, int* trsv_timeouts, int clear) {
+    ARG_CHECK(h != nullptr);
+    int* info = nullptr;
+    char* base = nullptr;
+    if (int rc = status_ws(h, &info, &base)) return rc;
+    int* pin = (int*)oisat_pinned(h, 256);
+    if (!pin) return OISAT_ENOMEM;
+    HIP_TRY(hipMemcpyAsync(pin, info, 4 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(pin + 4, base, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (clear) {
+        HIP_TRY(hipMemsetAsync(info + 1, 0, 2 * sizeof(int), h->stream));
+        HIP_TRY(hipMemsetAsync(base, 0, 16, h->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (first_notpd_col) *first_notpd_col = pin[1];
+    if (n_notpd_blocks) *n_notpd_blocks = pin[2];
+    if (trsv_timeouts) *trsv_timeouts = pin[4];
+    return OISAT_OK;
+}
+
+extern "C" int oisat_dense_reserve(oisat_ctx* h, int64_t max_obs, int64_t diag_chunk_rows) {
+    ARG_CHECK(h != nullptr && max_obs > 0 && diag_chunk_rows >= 0);
+    const int64_t mp = cdiv(max_obs, NB) * NB;
+    if (!oisat_ws(h, 3, sizeof(float) * mp * NB)) return OISAT_ENOMEM;                  // inverted diagonal blocks
+    if (int rc = status_ws(h, nullptr, nullptr)) return rc;                              // slots 4 and 7
+    if (!oisat_ws(h, 5, sizeof(double) * 2 * mp)) return OISAT_ENOMEM;                   // padded rhs + forward solution
+    size_t s6 = sizeof(double) * (max_obs + 16);                                         // refinement residual
+    if (diag_chunk_rows > 0) {
+        const int64_t ch = cdiv(diag_chunk_rows, NB) * NB;
+        const size_t x = sizeof(float) * ch * mp + sizeof(double) * ch;                 // posterior-error / gain-diag rows
+        if (x > s6) s6 = x;
+    }
+    if (!oisat_ws(h, 6, s6)) return OISAT_ENOMEM;
+    if (!oisat_pinned(h, 4096)) return OISAT_ENOMEM;
     return OISAT_OK;
 }

@@ -82,6 +82,8 @@ SIGNATURES = {
     "oisat_gain_diag": (C.c_int, [_c_ctx, _ptr, _i64, _i64, _ptr, _i64, _ptr]),
     "oisat_apply_increment": (C.c_int, [_c_ctx, C.c_int, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i64, C.c_double, _ptr,
                                         _ptr, _ptr, _ptr, _ptr]),
+    "oisat_solve_status": (C.c_int, [_c_ctx, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]),
+    "oisat_dense_reserve": (C.c_int, [_c_ctx, _i64, _i64]),
 }
 
 
@@ -252,6 +254,20 @@ class Context:
         hbm = _i64()
         self.check(self.lib.oisat_device_info(self.h, name, 128, C.byref(cu), C.byref(hbm)))
         return {"name": name.value.decode(), "cu_count": cu.value, "hbm_bytes": hbm.value}
+
+    def solve_status(self, clear=True):
+        """(first non-PD column, failing diagonal blocks, triangular-solve time-outs) since the last clear."""
+        a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
+        self.check(self.lib.oisat_solve_status(self.h, C.byref(a), C.byref(b), C.byref(c), 1 if clear else 0))
+        return a.value, b.value, c.value
+
+    def check_solves(self, what="dense analysis"):
+        """Raise ``OisatError`` if any unchecked dense solve on this handle failed since the last check."""
+        col, nblk, nto = self.solve_status(clear=True)
+        if col or nblk or nto:
+            raise OisatError(f"{what}: " + "; ".join(
+                ([f"H B H^T + R not positive definite (first bad column {col}, {nblk} diagonal block(s))"] if (col or nblk) else [])
+                + ([f"{nto} triangular-solve workgroup(s) gave up waiting: z holds NaN fill"] if nto else [])))
 
     # ---- profiling
     def prof_enable(self, on=True):

@@ -107,12 +107,13 @@ def averaging(startdate: str, enddate: str, reader_obj):
                         chosen["a2"].append(np.nan * g.vcd)
         mi, yi = month - m0, year - y0
         if len(chosen["vcd"]) != 0 and np.size(chosen["vcd"][0]) != 0:
-            dt = _hip.compute_dtype(*chosen["vcd"][:1], *chosen["err"][:1], *chosen["ctm"][:1])
+            # every granule counts, as np.array(list) would promote: one float64 granule makes the stack float64
+            dt = _hip.compute_dtype(*chosen["vcd"], *chosen["err"], *chosen["ctm"])
             sat_averaged_vcd[:, :, mi, yi] = _reduce_stack(ctx, chosen["vcd"], dt, "mean", True)
             sat_averaged_error[:, :, mi, yi] = _reduce_stack(ctx, chosen["err"], dt, "err", True)
             ctm_averaged_vcd[:, :, mi, yi] = _reduce_stack(ctx, chosen["ctm"], dt, "mean", False)
         if len(chosen["a1"]) != 0 and np.size(chosen["a1"][0]) != 0:
-            dt = _hip.compute_dtype(*chosen["a1"][:1], *chosen["a2"][:1])
+            dt = _hip.compute_dtype(*chosen["a1"], *chosen["a2"])
             sat_aux1[:, :, mi, yi] = _reduce_stack(ctx, chosen["a1"], dt, "mean", False)
             sat_aux2[:, :, mi, yi] = _reduce_stack(ctx, chosen["a2"], dt, "mean", False)
 

@@ -54,7 +54,11 @@ class DenseAnalysis:
     """Device-resident dense analysis for one grid: upload the grid once, then ``load_obs`` /
     ``run`` per month.  Buffers are sized at ``max_obs`` so nothing is allocated per analysis."""
 
-    def __init__(self, grid_lat, grid_lon, max_obs: int, dtype=np.float32, ctx=None, shared_S=None):
+    def __init__(self, grid_lat, grid_lon, max_obs: int, dtype=np.float32, ctx=None, shared_S=None, out_ptr=None,
+                 diag_chunk_rows: int = 0):
+        """``shared_S``: a factor buffer (``SharedFactor`` or device buffer) shared with other analyses that run one
+        after another on the same handle.  ``out_ptr``: device address of 2 n elements where ``xa | inc`` are to be
+        written (e.g. a slice of one slab that is gathered over RCCL); by default the plan owns them."""
         self.ctx = ctx or _hip.context()
         self.dt = np.dtype(dtype)
         self.code = _hip.dtype_code(self.dt)
@@ -66,7 +70,12 @@ class DenseAnalysis:
         self.gxyz = c.upload(unit_vectors(grid_lat, grid_lon))
         self.glat = c.upload(np.ravel(grid_lat), dtype=np.float64)       # latitude window of apply_increment
         item = self.dt.itemsize
-        self.fields = c.alloc(3 * self.n * item)            # xb | xa | inc
+        if out_ptr is None:
+            self.fields = c.alloc(3 * self.n * item)        # xb | xa | inc
+            self.xb_ptr, self.out_ptr = self.fields.at(0), self.fields.at(self.n * item)
+        else:
+            self.fields = c.alloc(self.n * item)            # xb; xa | inc live in the caller's slab
+            self.xb_ptr, self.out_ptr = self.fields.at(0), int(out_ptr)
         self.gsig = c.alloc(self.n * 8)
         m = self.max_obs
         self.oxyz = c.alloc(3 * m * 8)
@@ -83,11 +92,13 @@ class DenseAnalysis:
             raise ValueError("shared_S is too small for max_obs")
         self.m = 0
         self._direct_innovation = False
+        # every internal workspace of the solve is sized here, so that run() never allocates (include/oisat.h)
+        c.check(c.lib.oisat_dense_reserve(c.h, self.max_obs, int(diag_chunk_rows)))
 
     # ---- inputs
     def load_background(self, Xa, Sa, scale=1.0):
         c = self.ctx
-        c.upload_into(self.fields.at(0), np.ravel(Xa), dtype=self.dt)
+        c.upload_into(self.xb_ptr, np.ravel(Xa), dtype=self.dt)
         sig = np.sqrt(float(scale) * np.ravel(np.asarray(Sa, dtype=np.float64)))
         self._gsig_host = sig
         c.upload_into(self.gsig.ptr, sig, dtype=np.float64)
@@ -145,7 +156,7 @@ class DenseAnalysis:
         m, ld = self.m, self.mp
         g = self._g = decay_constant(L_km)
         item = self.dt.itemsize
-        xb, xa, inc = (self.fields.at(i * self.n * item) for i in range(3))
+        xb, xa, inc = self.xb_ptr, self.out_ptr, self.out_ptr + self.n * item
         if not self._direct_innovation:
             c.check(lib.oisat_innovation(h, self.code, xb, self.ocell.ptr, self.oy.ptr, m, self.d.ptr))
         c.check(lib.oisat_cov_build(h, self.oxyz.ptr, self.osig.ptr, self.ovar.ptr, m, g, self.S.ptr, ld))
@@ -178,11 +189,18 @@ class DenseAnalysis:
         return self._unsort(c.download(self._ak.ptr, (self.m,), np.float64))
 
     # ---- outputs
+    def check(self):
+        """Wait for this handle's stream and raise ``OisatError`` if any solve enqueued on it since the last check met a
+        non-positive pivot or a triangular-solve time-out (``run`` is asynchronous and unchecked by default)."""
+        self.ctx.check_solves()
+
     def download(self):
-        out = self.ctx.download(self.fields.at(self.n * self.dt.itemsize), (2,) + tuple(self.shape), self.dt)
+        self.check()
+        out = self.ctx.download(self.out_ptr, (2,) + tuple(self.shape), self.dt)
         return out[0], out[1]
 
     def download_z(self):
+        self.check()
         return self._unsort(self.ctx.download(self.z.ptr, (self.m,), np.float64))
 
     def download_S(self):
@@ -226,74 +244,152 @@ def tile_partition(lat2, lon2, obs_lat, obs_lon, tile_deg=30.0, halo_km=900.0):
     return tiles
 
 
+class SharedFactor:
+    """The factor workspace of one lane: analyses that run back to back on a handle share it.  Grow-only; it may be
+    re-allocated between (never during) runs, which is why plans hold this object and read ``.ptr`` at run time."""
+
+    def __init__(self, lane):
+        self.lane = lane
+        self.buf = None
+        self.nbytes = 0
+
+    def reserve(self, max_obs: int):
+        mp = -(-max(int(max_obs), 1) // NB) * NB
+        need = mp * mp * 4
+        if need > self.nbytes:
+            if self.buf is not None:
+                self.lane.sync()
+                self.buf.free()
+            self.buf = self.lane.alloc(need)
+            self.nbytes = need
+        return self
+
+    @property
+    def ptr(self):
+        return self.buf.ptr
+
+
+class LanePool:
+    """Several handles on ONE device, each with its own stream, workspaces and shared factor buffer.  Tiles and
+    months are independent, and a 4,000-8,000-observation solve leaves most of the 256 CUs idle on its own."""
+
+    def __init__(self, ctx=None, streams: int = 12):
+        self.ctx = ctx or _hip.context()
+        self.lanes = [self.ctx] + [_hip.Context(self.ctx.device).own_stream() for _ in range(max(0, int(streams) - 1))]
+        self.factors = [SharedFactor(lane) for lane in self.lanes]
+
+    def __len__(self):
+        return len(self.lanes)
+
+    def assign(self, weights):
+        """Longest-processing-time-first: heaviest unit to the least loaded lane.  -> (lane of each unit, run order)."""
+        order = sorted(range(len(weights)), key=lambda i: (-float(weights[i]), i))
+        load = [0.0] * len(self.lanes)
+        lane_of = [0] * len(weights)
+        for i in order:
+            li = min(range(len(load)), key=load.__getitem__)
+            lane_of[i] = li
+            load[li] += float(weights[i])
+        return lane_of, order
+
+    def sync(self):
+        for lane in self.lanes:
+            lane.sync()
+
+    def check(self, what="tiled analysis"):
+        for lane in self.lanes:
+            lane.check_solves(what)
+
+    def close(self):
+        for f in self.factors:
+            if f.buf is not None:
+                f.buf.free()
+        for lane in self.lanes[1:]:
+            lane.close()
+
+
 class TiledAnalysis:
     """Localised block-B analysis: one small dense analysis per tile (its own S = H B H^T + R over the
-    tile's observations + halo), run back to back on the stream with ONE shared factor workspace.
-    Tiles are independent work units -- ``parallel.shard_units`` spreads (month x tile) over GPUs."""
+    tile's observations + halo).  Tiles are independent work units: inside one GPU they are dealt to the lanes of a
+    ``LanePool`` (heaviest first, each lane one stream with ONE shared factor workspace); across GPUs
+    ``parallel.shard_units`` spreads (month x tile) units -- ``only`` restricts this object to the tiles a rank owns."""
 
-    def __init__(self, grid_lat, grid_lon, tile_deg=30.0, halo_km=900.0, dtype=np.float32, ctx=None, streams=12):
-        self.ctx = ctx or _hip.context()
-        # extra handles on the same device, each with its own stream, workspaces and factor: tiles are
-        # independent, and a 4,000-8,000-observation solve leaves most of the 256 CUs idle on its own
-        self.lanes = [self.ctx] + [_hip.Context(self.ctx.device).own_stream() for _ in range(max(0, int(streams) - 1))]
+    def __init__(self, grid_lat, grid_lon, tile_deg=30.0, halo_km=900.0, dtype=np.float32, ctx=None, streams=12, pool=None):
+        self.pool = pool or LanePool(ctx, streams)
+        self.ctx = self.pool.ctx
+        self.lanes = self.pool.lanes
         self.lat2, self.lon2 = np.asarray(grid_lat), np.asarray(grid_lon)
         self.tile_deg, self.halo_km = float(tile_deg), float(halo_km)
         self.dt = np.dtype(dtype)
         self.plans = []
 
-    def load(self, Xa, Sa, obs_lat, obs_lon, obs_y, obs_var, scale=1.0):
+    def prepare(self, Xa, Sa, obs_lat, obs_lon, obs_y, obs_var, scale=1.0, only=None):
+        """Host side: cut the month into tiles, innovation against the GLOBAL background.  ``only``: the tile indices
+        this object analyses (default all).  -> the live tile indices and their observation counts."""
         Xa = np.asarray(Xa, dtype=np.float64)
         sig = np.sqrt(float(scale) * np.asarray(Sa, dtype=np.float64))
         olat, olon = np.ravel(obs_lat), np.ravel(obs_lon)
         cell = regular_grid_cell(self.lat2, self.lon2, olat, olon)
         y = np.where(np.ravel(obs_y) < 0, 0.0, np.ravel(obs_y))
-        d_all = y - Xa.ravel()[cell]                         # innovation against the GLOBAL background
-        s_all = sig.ravel()[cell]
-        ovar = np.ravel(obs_var)
-        self.tiles = [t for t in tile_partition(self.lat2, self.lon2, olat, olon, self.tile_deg, self.halo_km)]
-        # largest tiles first, each to the lane with the least factorization work so far (cost ~ m^3);
-        # a lane is one stream with one shared factor workspace
-        order = sorted(range(len(self.tiles)), key=lambda i: -self.tiles[i]["obs"].size)
-        load = [0.0] * len(self.lanes)
-        lane_of = {}
-        for ti in order:
-            li = min(range(len(load)), key=load.__getitem__)
-            lane_of[ti] = li
-            load[li] += float(self.tiles[ti]["obs"].size) ** 3
-        self.S = []
-        for li, lane in enumerate(self.lanes):
-            mmax = max((self.tiles[ti]["obs"].size for ti in order if lane_of[ti] == li), default=0)
-            mp = -(-max(int(mmax), 1) // NB) * NB
-            self.S.append(lane.alloc(mp * mp * 4))
-        self.plans = []
+        self._host = dict(Xa=Xa, Sa=np.asarray(Sa), scale=float(scale), olat=olat, olon=olon, ovar=np.ravel(obs_var),
+                          d=y - Xa.ravel()[cell], s=sig.ravel()[cell])
+        self.tiles = tile_partition(self.lat2, self.lon2, olat, olon, self.tile_deg, self.halo_km)
+        nx = self.lat2.shape[1]
+        self._cell, self._Sa, self._scale = cell, np.asarray(Sa), float(scale)
+        self._inside = [None] * len(self.tiles)
         for ti, t in enumerate(self.tiles):
             (y0, y1), (x0, x1) = t["rows"], t["cols"]
-            if t["obs"].size == 0:
-                self.plans.append(None)
-                continue
-            li = lane_of[ti]
-            p = DenseAnalysis(self.lat2[y0:y1, x0:x1], self.lon2[y0:y1, x0:x1], max_obs=int(t["obs"].size), dtype=self.dt,
-                              ctx=self.lanes[li], shared_S=self.S[li])
-            p.load_background(Xa[y0:y1, x0:x1], np.asarray(Sa)[y0:y1, x0:x1], scale=scale)
-            o = t["obs"]
-            p.load_obs_direct(olat[o], olon[o], s_all[o], ovar[o], d_all[o])
-            self.plans.append(p)
+            c = cell[t["obs"]]
+            self._inside[ti] = (c // nx >= y0) & (c // nx < y1) & (c % nx >= x0) & (c % nx < x1)
+        keep = set(range(len(self.tiles))) if only is None else set(int(t) for t in only)
+        self.live = [ti for ti, t in enumerate(self.tiles) if ti in keep and t["obs"].size]
         self._Xa = Xa
         self.n = int(Xa.size)
-        self.flops = sum(DenseAnalysis.flops(int(t["obs"].size)) for t in self.tiles if t["obs"].size)
+        self.flops = sum(DenseAnalysis.flops(int(self.tiles[ti]["obs"].size)) for ti in self.live)
+        return self.live, [int(self.tiles[ti]["obs"].size) for ti in self.live]
 
-        self._order = [ti for ti in order if self.plans[ti] is not None]
+    def build(self, lane_of=None, order=None, out_ptrs=None):
+        """Device side: one plan per live tile on its lane.  ``lane_of`` / ``order``: per live tile (default: LPT by
+        obs^3 over this object's tiles alone); ``out_ptrs``: per live tile, where its ``xa | inc`` go."""
+        h = self._host
+        sizes = [int(self.tiles[ti]["obs"].size) for ti in self.live]
+        if lane_of is None:
+            lane_of, order = self.pool.assign([float(m) ** 3 for m in sizes])
+        for k, m in enumerate(sizes):
+            self.pool.factors[lane_of[k]].reserve(m)
+        self.plans = [None] * len(self.tiles)
+        for k, ti in enumerate(self.live):
+            t = self.tiles[ti]
+            (y0, y1), (x0, x1) = t["rows"], t["cols"]
+            li = lane_of[k]
+            p = DenseAnalysis(self.lat2[y0:y1, x0:x1], self.lon2[y0:y1, x0:x1], max_obs=sizes[k], dtype=self.dt,
+                              ctx=self.lanes[li], shared_S=self.pool.factors[li],
+                              out_ptr=None if out_ptrs is None else out_ptrs[k])
+            p.load_background(h["Xa"][y0:y1, x0:x1], h["Sa"][y0:y1, x0:x1], scale=h["scale"])
+            o = t["obs"]
+            p.load_obs_direct(h["olat"][o], h["olon"][o], h["s"][o], h["ovar"][o], h["d"][o])
+            self.plans[ti] = p
+        self._order = [self.live[k] for k in (order if order is not None else range(len(self.live)))]
+        self._host = None
 
-    def run(self, L_km, refine=1, check_pd=False):
-        """Enqueue every tile on its lane's stream (largest first) and wait for all lanes."""
-        main_stream_work = self.ctx
-        main_stream_work.sync()                         # inputs uploaded on the default stream are complete
+    def load(self, Xa, Sa, obs_lat, obs_lon, obs_y, obs_var, scale=1.0, only=None):
+        self.prepare(Xa, Sa, obs_lat, obs_lon, obs_y, obs_var, scale=scale, only=only)
+        self.build()
+
+    def enqueue(self, L_km, refine=1, check_pd=False):
         for ti in self._order:
             self.plans[ti].run(L_km, refine=refine, check_pd=check_pd)
-        for lane in self.lanes:
-            lane.sync()
+
+    def run(self, L_km, refine=1, check_pd=False):
+        """Enqueue every tile on its lane's stream (largest first), wait for all lanes and check their solve status:
+        a non-positive pivot or a triangular-solve time-out in ANY tile raises ``OisatError``."""
+        self.ctx.sync()                                 # inputs uploaded on the default stream are complete
+        self._L, self._refine = float(L_km), int(refine)
+        self.enqueue(L_km, refine=refine, check_pd=check_pd)
+        self.pool.check("tiled analysis")
 
     def download(self):
+        """(xa, inc) on the full grid; cells of tiles this object does not own keep the background / zero."""
         xa = self._Xa.astype(self.dt).copy()
         inc = np.zeros_like(xa)
         for t, p in zip(self.tiles, self.plans):
@@ -304,6 +400,84 @@ class TiledAnalysis:
             xa[y0:y1, x0:x1] = a
             inc[y0:y1, x0:x1] = b
         return xa, inc
+
+    def download_error(self, chunk_rows: int = 4096):
+        """Posterior error sqrt(diag(B - B H^T S^-1 H B)) on the full grid and diag(K H) per cell (sum over the
+        observations inside the cell; 0 where none), tile by tile from each tile's own factor.  A lane shares one
+        factor buffer between its tiles, so every tile is re-run (check_pd) right before its diagnostics."""
+        err = np.sqrt(self._scale * np.asarray(self._Sa, dtype=np.float64)).astype(np.float32)
+        ak = np.zeros(self._Xa.size)
+        for ti in self._order:
+            t, p = self.tiles[ti], self.plans[ti]
+            (y0, y1), (x0, x1) = t["rows"], t["cols"]
+            p.run(self._L, refine=self._refine, check_pd=True)
+            err[y0:y1, x0:x1] = p.posterior_error(chunk_rows)
+            a = p.gain_diag(chunk_rows)
+            inside = self._inside[ti]                    # halo observations belong to another tile's cells
+            np.add.at(ak, self._cell[t["obs"]][inside], a[inside])
+        return err, ak.reshape(self._Xa.shape)
+
+
+class MonthTileBatch:
+    """BASELINE configs[3] -- several monthly analyses cut into (month x tile) work units -- as ONE GPU sees it: the
+    units this rank owns, of whatever months, dealt to the lanes of one pool by a single LPT pass and run without any
+    host synchronisation in between; every unit writes its ``xa | inc`` tile into one contiguous slab, which is what
+    ``parallel`` gathers to rank 0 in a single message.  (Reference: one scheduler job per month,
+    run/job_submitter_sbatch.py:45-68; months alone cap 8 GPUs at 12/2 = 6x, hence the finer unit.)"""
+
+    def __init__(self, grid_lat, grid_lon, tile_deg=30.0, halo_km=900.0, dtype=np.float32, ctx=None, streams=12):
+        self.pool = LanePool(ctx, streams)
+        self.ctx = self.pool.ctx
+        self.lat2, self.lon2 = np.asarray(grid_lat), np.asarray(grid_lon)
+        self.tile_deg, self.halo_km, self.dt = float(tile_deg), float(halo_km), np.dtype(dtype)
+        self.months = {}                                # key -> TiledAnalysis restricted to the owned tiles
+        self.units = []                                 # (month key, tile index, nobs) in insertion order
+
+    def add_month(self, key, Xa, Sa, obs_lat, obs_lon, obs_y, obs_var, scale=1.0, only=None):
+        ta = TiledAnalysis(self.lat2, self.lon2, self.tile_deg, self.halo_km, self.dt, pool=self.pool)
+        live, sizes = ta.prepare(Xa, Sa, obs_lat, obs_lon, obs_y, obs_var, scale=scale, only=only)
+        self.months[key] = ta
+        self.units += [(key, ti, m) for ti, m in zip(live, sizes)]
+
+    def build(self, min_slab_elems: int = 0):
+        item = self.dt.itemsize
+        lane_of, order = self.pool.assign([float(m) ** 3 for (_, _, m) in self.units])
+        for li, (_, _, m) in zip(lane_of, self.units):
+            self.pool.factors[li].reserve(m)
+        self.offsets, total = [], 0                      # element offset of each unit's xa|inc inside the slab
+        for key, ti, _ in self.units:
+            (y0, y1), (x0, x1) = self.months[key].tiles[ti]["rows"], self.months[key].tiles[ti]["cols"]
+            self.offsets.append(total)
+            total += 2 * (y1 - y0) * (x1 - x0)
+        self.slab_elems = total
+        self.slab = self.ctx.alloc(max(total, int(min_slab_elems), 1) * item)
+        self.ctx.check(self.ctx.lib.oisat_memset(self.ctx.h, self.slab.ptr, 0, self.slab.nbytes))
+        k0 = 0
+        for key, ta in self.months.items():              # units of one month are contiguous in self.units
+            nk = len(ta.live)
+            ta.build(lane_of=lane_of[k0:k0 + nk], order=None,
+                     out_ptrs=[self.slab.at(self.offsets[k] * item) for k in range(k0, k0 + nk)])
+            k0 += nk
+        self._run_order = [self.units[i][:2] for i in order]
+        self.flops = sum(ta.flops for ta in self.months.values())
+
+    def run(self, L_km, refine=1, check_pd=False, wait=True):
+        self.ctx.sync()
+        for key, ti in self._run_order:                  # heaviest unit first, across months
+            self.months[key].plans[ti].run(L_km, refine=refine, check_pd=check_pd)
+        if wait:
+            self.pool.check("month x tile batch")
+
+    def unit_shape(self, k):
+        key, ti, _ = self.units[k]
+        (y0, y1), (x0, x1) = self.months[key].tiles[ti]["rows"], self.months[key].tiles[ti]["cols"]
+        return (2, y1 - y0, x1 - x0)
+
+    def download_slab(self):
+        return self.ctx.download(self.slab.ptr, (self.slab_elems,), self.dt)
+
+    def close(self):
+        self.pool.close()
 
 
 def OI_dense(Xa, Y, Sa, So, lat, lon, L_km, scale=1.0, refine=2, obs=None, dtype=None, want_error=False):
@@ -337,7 +511,7 @@ def OI_dense(Xa, Y, Sa, So, lat, lon, L_km, scale=1.0, refine=2, obs=None, dtype
                      "ak_obs": np.empty(0)}
         return (np.array(Xa, dtype=dt), np.zeros(np.shape(Xa), dtype=dt),
                 {"nobs": 0, "residuals": [], "cells": cell, "z": np.empty(0), **extra})
-    plan = DenseAnalysis(lat, lon, max_obs=int(cell.size), dtype=dt)
+    plan = DenseAnalysis(lat, lon, max_obs=int(cell.size), dtype=dt, diag_chunk_rows=4096 if want_error else 0)
     xa_f = np.where(np.isfinite(Xa), Xa, 0.0)
     sa_f = np.where(np.isfinite(Sa), Sa, 0.0)
     plan.load_background(xa_f, sa_f, scale=scale)
@@ -346,11 +520,52 @@ def OI_dense(Xa, Y, Sa, So, lat, lon, L_km, scale=1.0, refine=2, obs=None, dtype
     xb, inc = plan.download()
     extra = {}
     if want_error:                     # the other two members of OI's 4-tuple: averaging kernel and sqrt(Sb)
+        # diag(K H) at a cell = sum over the observations INSIDE that cell of diag(H K) at the observation
+        # ((B H^T S^-1)[cell(a), a] = (H B H^T S^-1)[a, a]); with one observation per cell -- the reference's
+        # case -- this is AK of optimal_interpolation.py:31.  np.add.at: deterministic for repeated cells.
+        ak_obs = plan.gain_diag()
+        ak_sum = np.zeros(Xa.size)
+        np.add.at(ak_sum, cell, ak_obs)
         ak = np.full(Xa.size, np.nan)
-        ak[cell] = plan.gain_diag()    # (several obs in one cell: the last one wins)
-        extra = {"ak": ak.reshape(np.shape(Xa)), "err": plan.posterior_error(), "ak_obs": plan.gain_diag()}
+        ak[cell] = ak_sum[cell]
+        extra = {"ak": ak.reshape(np.shape(Xa)), "err": plan.posterior_error(), "ak_obs": ak_obs}
     bad = ~np.isfinite(Xa)
     if bad.any():
         xb = xb.copy()
         xb[bad] = np.nan
     return xb, inc, {"nobs": int(cell.size), "residuals": resid, "cells": cell, "z": plan.download_z(), **extra}
+
+
+def OI_tiled(Xa, Y, Sa, So, lat, lon, L_km, tile_deg=30.0, halo_km=None, scale=1.0, refine=2, dtype=None, want_error=False,
+             streams=12):
+    """Localised block-B analysis with the reference's gridded argument convention (see ``OI_dense``): the grid is cut
+    into ``tile_deg`` tiles, each analysed with the observations inside it or within ``halo_km`` (default 3 L).
+    Returns ``(Xb, increment, info)``; ``info`` carries ``ak`` / ``err`` when ``want_error``."""
+    Xa = np.asarray(Xa)
+    Y[Y < 0] = 0.0                                            # same clamp as optimal_interpolation.py:14
+    ok = np.isfinite(np.ravel(Y)) & np.isfinite(np.ravel(So)) & np.isfinite(np.ravel(Xa)) & np.isfinite(np.ravel(Sa))
+    cell = np.flatnonzero(ok)
+    dt = np.dtype(dtype) if dtype is not None else _hip.compute_dtype(Xa)
+    if cell.size == 0:
+        return OI_dense(Xa, Y, Sa, So, lat, lon, L_km, scale=scale, dtype=dt, want_error=want_error)
+    xa_f = np.where(np.isfinite(Xa), Xa, 0.0)
+    sa_f = np.where(np.isfinite(Sa), Sa, 0.0)
+    ta = TiledAnalysis(lat, lon, tile_deg=tile_deg, halo_km=3.0 * float(L_km) if halo_km is None else halo_km, dtype=dt,
+                       streams=streams)
+    try:
+        ta.load(xa_f, sa_f, np.ravel(lat)[cell], np.ravel(lon)[cell], np.ravel(Y)[cell], np.ravel(So)[cell], scale=scale)
+        ta.run(L_km, refine=refine, check_pd=True)
+        xb, inc = ta.download()
+        extra = {}
+        if want_error:
+            err, ak = ta.download_error()
+            akf = np.full(Xa.size, np.nan)
+            akf[cell] = ak.ravel()[cell]
+            extra = {"ak": akf.reshape(np.shape(Xa)), "err": err}
+    finally:
+        ta.pool.close()
+    bad = ~np.isfinite(Xa)
+    if bad.any():
+        xb = xb.copy()
+        xb[bad] = np.nan
+    return xb, inc, {"nobs": int(cell.size), "cells": cell, "tiles": len(ta.tiles), **extra}

@@ -58,13 +58,82 @@ class oisatgmi(object):
         offset, slope = corr
         self.sat_averaged_vcd = (self.sat_averaged_vcd - offset) / slope
 
+    # ---- analysis mode (extension; the signature of oi() is the reference's) -----------------------------
+    #   mode        attribute `oi_mode`        | env OISAT_OI_MODE        diag (default) | dense | tiled
+    #   L           attribute `corr_length_km` | env OISAT_CORR_LENGTH_KM km, default 300           (dense, tiled)
+    #   tile size   attribute `tile_deg`       | env OISAT_TILE_DEG       degrees, default 30       (tiled; halo = 3 L)
+    #   unobserved  attribute `oi_unobserved`  | env OISAT_UNOBSERVED     nan (default) | xa        (dense, tiled)
+    #   grid        attributes `grid_lat`, `grid_lon` (ny, nx), else the first granule's latitude_center/longitude_center
+    #   knee        attribute `oi_reg_index`: force the index into the 99-scaling sweep (all modes)
+    def _oi_setting(self, attr, env, default, cast=str):
+        v = getattr(self, attr, None)
+        if v is None:
+            v = os.environ.get(env)
+        return cast(default if v in (None, "") else v)
+
+    def _oi_grid(self):
+        lat, lon = getattr(self, "grid_lat", None), getattr(self, "grid_lon", None)
+        if lat is None or lon is None:
+            first = next(g for g in self.reader_obj.sat_data if g is not None)
+            lat, lon = first.latitude_center, first.longitude_center
+        return np.asarray(lat, dtype=np.float64), np.asarray(lon, dtype=np.float64)
+
     def oi(self, sensor: str, error_ctm=50.0):
+        """driver.py:108-114.  Default (``diag``): the reference's element-wise analysis.  ``dense`` / ``tiled``: the
+        Gaussian-B generalisation x_a = x_b + B H^T (H B H^T + R)^-1 (y - H x_b) with B = s D^1/2 C D^1/2 -- global, or
+        localised to tiles with a 3 L halo; D = diag(Sa) and R = diag(So) are the reference's variances, s is the
+        regularisation factor picked by the reference's own knee sweep over the element-wise curve
+        (optimal_interpolation.py:15-41), and L -> 0 reproduces the ``diag`` attributes at observed cells.  The same
+        four attributes are filled.  Unobserved cells: ``nan`` (default) keeps the reference's convention -- NaN in all
+        four fields, optimal_interpolation.py:49-50 with Y = NaN; ``xa`` keeps what the dense analysis really says there:
+        background + spread increment, posterior error, averaging kernel 0."""
         if sensor != 'GOSAT':
             xa, y = self.ctm_averaged_vcd, self.sat_averaged_vcd
         else:
             xa, y = self.aux2, self.aux1
-        self.ctm_averaged_vcd_corrected, self.ak_OI, self.increment_OI, self.error_OI = OI(
-            xa, y, (xa * error_ctm / 100.0) ** 2, self.sat_averaged_error ** 2, regularization_on=True)
+        Sa, So = (xa * error_ctm / 100.0) ** 2, self.sat_averaged_error ** 2
+        mode = self._oi_setting("oi_mode", "OISAT_OI_MODE", "diag").lower()
+        reg_index = getattr(self, "oi_reg_index", None)
+        if mode == "diag":
+            self.ctm_averaged_vcd_corrected, self.ak_OI, self.increment_OI, self.error_OI = OI(
+                xa, y, Sa, So, regularization_on=True, reg_index=reg_index)
+            return
+        if mode not in ("dense", "tiled"):
+            raise ValueError(f"OISAT_OI_MODE / oi_mode must be diag, dense or tiled, not {mode!r}")
+        from . import dense
+        from . import optimal_interpolation as oi_mod
+        L = self._oi_setting("corr_length_km", "OISAT_CORR_LENGTH_KM", 300.0, float)
+        unobserved = self._oi_setting("oi_unobserved", "OISAT_UNOBSERVED", "nan").lower()
+        if unobserved not in ("nan", "xa"):
+            raise ValueError(f"OISAT_UNOBSERVED / oi_unobserved must be nan or xa, not {unobserved!r}")
+        lat, lon = self._oi_grid()
+        print('Optimal interpolation begins...')
+        y[y < 0] = 0.0                                           # in place, optimal_interpolation.py:14
+        index, scale, curve, found = oi_mod.regularization_pick(Sa, So, reg_index)
+        print("The regularization factor is " + str(scale))
+        if mode == "dense":
+            xb, inc, info = dense.OI_dense(xa, y, Sa, So, lat, lon, L, scale=scale, want_error=True)
+        else:
+            tile = self._oi_setting("tile_deg", "OISAT_TILE_DEG", 30.0, float)
+            xb, inc, info = dense.OI_tiled(xa, y, Sa, So, lat, lon, L, tile_deg=tile, scale=scale, want_error=True)
+        xb, inc = np.array(xb, dtype=np.float64), np.array(inc, dtype=np.float64)
+        err, ak = np.array(info["err"], dtype=np.float64), np.array(info["ak"], dtype=np.float64)
+        # cells the reference's OI gives numbers for: y, So, xa, Sa all non-NaN.  So = +inf there means K = 0 (no weight):
+        # the dense analysis simply does not use such an observation, and AK = 0 as in the reference; Sa*reg = 0 makes the
+        # reference's AK = 1 - Sb/(Sa*reg) a 0/0 (optimal_interpolation.py:31): mirrored.
+        observed = np.isfinite(y) & ~np.isnan(So) & np.isfinite(xa) & np.isfinite(Sa)
+        ak[observed & np.isinf(So)] = 0.0
+        ak[observed & (Sa * scale == 0)] = np.nan
+        if unobserved == "nan":
+            for a in (xb, inc, err, ak):
+                a[~observed] = np.nan
+        else:
+            ak[~observed & np.isfinite(xa)] = 0.0
+            for a in (inc, err, ak):
+                a[~np.isfinite(xa)] = np.nan
+        self.ctm_averaged_vcd_corrected, self.ak_OI, self.increment_OI, self.error_OI = xb, ak, inc, err
+        self.oi_info = {"mode": mode, "corr_length_km": L, "scale": scale, "reg_index": index, "knee_found": found,
+                        "nobs": info["nobs"], "unobserved": unobserved}
 
     def scaling_factor(self):
         """posterior / prior model column with NaN, inf and 0 mapped to 1.0 -- the field the downstream

@@ -36,6 +36,29 @@ def _curve(ctx, code, dSa, dSo, n, factors):
     return mean, cnt
 
 
+def regularization_pick(Sa, So, reg_index=None, ctx=None):
+    """The reference's regularisation choice by itself (optimal_interpolation.py:15-41): the 99-scaling sweep of the
+    element-wise averaging-kernel mean on the device, then the knee pick (or ``reg_index``).  -> (index, scale, curve,
+    knee_found).  Used by the dense / tiled analysis modes, which take their prior-error scaling from it."""
+    ctx = ctx or _hip.context()
+    dt = _hip.compute_dtype(Sa, So)
+    n = int(np.size(Sa))
+    buf = ctx.alloc(2 * n * dt.itemsize)
+    ctx.upload_into(buf.at(0), np.ravel(Sa), dtype=dt)
+    ctx.upload_into(buf.at(n * dt.itemsize), np.ravel(So), dtype=dt)
+    factors = scaling_factors(True)
+    curve, _ = _curve(ctx, _hip.dtype_code(dt), buf.at(0), buf.at(n * dt.itemsize), n, factors)
+    buf.free()
+    found = False
+    if reg_index is None:
+        k = knee_index(factors, curve)
+        found = k is not None
+        index = 0 if k is None else int(k)
+    else:
+        index = int(reg_index)
+    return index, float(factors[index]), curve, found
+
+
 class DiagOI:
     """Device-resident element-wise OI: fields stay in HBM between calls (what ``OI`` does per call,
     minus the PCIe copies).  ``load`` once, ``run`` many times; ``download`` when needed."""

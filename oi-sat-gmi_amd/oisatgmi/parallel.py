@@ -114,17 +114,19 @@ class FieldGather:
 
     def __init__(self, plan, world, rank, local_rank):
         import torch
-        self.world, self.rank = world, rank
+        self.world, self.rank, self.plan = world, rank, plan
         item = plan.dt.itemsize
         typestr = "<f4" if item == 4 else "<f8"
-        view = _DevView(plan.fields.at(plan.n * item), 2 * plan.n, typestr)
+        view = _DevView(plan.out_ptr, 2 * plan.n, typestr)
         self.send = torch.as_tensor(view, device=torch.device("cuda", local_rank))
         # only the root holds the receive slab
         self.slab = torch.empty((world, 2 * plan.n), dtype=self.send.dtype, device=self.send.device) if rank == 0 else None
         self.shape = plan.shape
 
     def run(self):
-        """xa|inc of this rank's month -> rank 0 (a gather, not an all-gather: nobody else needs them)."""
+        """xa|inc of this rank's month -> rank 0 (a gather, not an all-gather: nobody else needs them).  The solve
+        status of the handle is checked first (one 20-byte read-back), so a failed unchecked run never travels."""
+        self.plan.check()
         dist = _dist()
         parts = [self.slab[r] for r in range(self.world)] if self.rank == 0 else None
         dist.gather(self.send, gather_list=parts, dst=0)

@@ -242,6 +242,43 @@ def swath_granule(seed: int, nscan: int = 240, npix: int = 60, lat0: float = -20
                          np.empty((1)), np.empty((1)), False, [], [], [], [])
 
 
+def swath_level_granule(seed: int, kind: str = "amf", nz: int = 3, nscan: int = 120, npix: int = 40, lat0: float = -5.0,
+                        lat1: float = 25.0, lon_c: float = 10.0, width_deg: float = 10.0):
+    """One small L2 swath that carries the per-level cubes ``interpolator()`` regrids level by level
+    (interpolator.py:191-283): ``kind='amf'`` -> ``satellite_amf`` with scattering weights + pressure_mid (OMI-NO2
+    style, reader.py:874-883) and a tropopause field; ``'MOPITT'`` / ``'GOSAT'`` -> ``satellite_opt`` with averaging
+    kernels (nz+1 rows for MOPITT, nz for GOSAT), a-priori profile, pressure weights (GOSAT), a-priori column /
+    surface, surface pressure and x_col.  Cubes are level-major (nz, nscan, npix); a block of pixels is flagged bad."""
+    from .config import satellite_amf, satellite_opt
+    rng = np.random.default_rng(seed)
+    t = np.linspace(0.0, 1.0, nscan)[:, None]
+    s = np.linspace(-0.5, 0.5, npix)[None, :]
+    lat = lat0 + (lat1 - lat0) * t + 0.6 * s + rng.normal(scale=0.01, size=(nscan, npix))
+    lon = lon_c + 4.0 * (t - 0.5) + width_deg * s + rng.normal(scale=0.01, size=(nscan, npix))
+    shape = lat.shape
+    vcd = 2.0 + np.sin(np.deg2rad(6 * lon)) * np.cos(np.deg2rad(5 * lat)) + 0.05 * rng.normal(size=shape)
+    unc = rng.uniform(0.1, 0.6, size=shape)
+    qf = np.ones(shape)
+    qf[nscan // 3: nscan // 3 + nscan // 8, npix // 4: npix // 2] = 0.3
+    when = _dt.datetime(2019, 6, 15, 13, 45)
+    smooth = 1.0 + 0.3 * np.sin(np.deg2rad(7 * lon + 3 * lat))
+    pmid = np.linspace(950.0, 120.0, nz)[:, None, None] * (1.0 + 0.01 * rng.normal(size=(nz,) + shape))
+    if kind == "amf":
+        amf = 1.0 + 0.5 * np.cos(np.deg2rad(lat)) + 0.01 * rng.normal(size=shape)
+        sw = (np.linspace(0.4, 1.8, nz)[:, None, None] * smooth[None]).astype(np.float32)      # float32 cubes, as the readers hand over
+        trop = 200.0 + 50.0 * np.cos(np.deg2rad(3 * lat)) + rng.normal(size=shape)
+        return satellite_amf(vcd, amf, when, trop, lat, lon, [], [], unc, qf, pmid.astype(np.float32), sw, False, [], [], [], [])
+    nak = nz + 1 if kind == "MOPITT" else nz
+    ak = np.linspace(0.2, 1.2, nak)[:, None, None] * smooth[None] + 0.01 * rng.normal(size=(nak,) + shape)
+    apro = np.linspace(90.0, 40.0, nz)[:, None, None] * smooth[None]
+    pw = np.empty((1))
+    if kind == "GOSAT":
+        pw = np.full((nz,) + shape, 1.0 / nz) * (1.0 + 0.05 * rng.normal(size=(nz,) + shape))
+    return satellite_opt(vcd, when, [], np.empty((1)), lat, lon, [], [], unc, qf, pmid, ak, False, [], [], [],
+                         18.0 + 0.2 * smooth, apro, 1000.0 - 20.0 * smooth, 80.0 * smooth,
+                         1800.0 + 40.0 * smooth + rng.normal(size=shape), pw, kind)
+
+
 def regional_ctm_grid(lat0: float, lat1: float, lon0: float, lon1: float, dlat: float, dlon: float):
     """Model-grid coordinate dict in the layout the readers hand to ``interpolator``
     (``{'Latitude': 2-D, 'Longitude': 2-D}``, interpolator.py:117-118)."""

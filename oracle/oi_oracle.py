@@ -347,9 +347,12 @@ def upscaler(X, Y, Z, ctm_models_coordinate, grid_size, threshold, error=False):
 
 def interpolator(interpolator_type, grid_size, sat_data, ctm_models_coordinate, flag_thresh=0.75,
                  record_type=None):
-    """``interpolator`` (interpolator.py:100-291), 2-D field path of a ``satellite_amf`` record
-    (vcd, amf, tropopause if array, uncertainty) and its per-level cubes, interpolator types 1-4.
-    Returns a ``record_type`` (positional, :289-290) or None."""
+    """``interpolator`` (interpolator.py:100-291) for both record kinds, interpolator types 1-4: the 2-D fields
+    (vcd, amf, tropopause if array, uncertainty; :162-188), the per-level scattering-weight / pressure loops of a
+    ``satellite_amf`` record (:191-213) and the ``satellite_opt`` branch (:216-283: a-priori column, surface pressure,
+    a-priori surface, x_col, averaging kernels -- nz+1 rows for MOPITT, nz for GOSAT --, pressure weights (GOSAT only),
+    pressure_mid, a-priori profile).  A record with an ``x_col`` attribute is taken as ``satellite_opt``.
+    Returns a ``record_type`` (positional, :284-290) or None."""
     if interpolator_type not in (1, 2, 3, 4):
         raise Exception("other type of interpolation methods has not been implemented yet")
     clat = ctm_models_coordinate["Latitude"]
@@ -389,13 +392,36 @@ def interpolator(interpolator_type, grid_size, sat_data, ctm_models_coordinate, 
         ux, uy, vcd, need = regrid(sat_data.vcd * mask)
         if np.isnan(np.nanmean(vcd.flatten())):
             return None
-        _, _, amf, _ = regrid(sat_data.amf * mask)
+        is_opt = hasattr(sat_data, "x_col")
+        if not is_opt:
+            _, _, amf, _ = regrid(sat_data.amf * mask)                          # :169-173 (satellite_amf only)
         if np.size(sat_data.tropopause) != 1:
             _, _, trop, _ = regrid(sat_data.tropopause * mask)
         else:
             trop = np.empty((1))
         _, _, unc, _ = regrid(sat_data.uncertainty ** 2 * mask, error=True)
         unc = np.sqrt(unc)
+        if is_opt:                                                              # interpolator.py:216-287
+            def levels(cube, count):
+                return np.stack([regrid(np.squeeze(np.asarray(cube)[z]) * mask)[2] for z in range(count)])
+            nz = np.shape(sat_data.pressure_mid)[0]
+            single = {}
+            for nm in ("aprior_column", "surface_pressure", "apriori_surface"):  # each only `if field.any()` (:219-235)
+                if getattr(sat_data, nm).any():
+                    single[nm] = regrid(getattr(sat_data, nm) * mask)[2]
+            x_col = regrid(sat_data.x_col * mask)[2]                             # :237-240
+            if sat_data.sensor == 'MOPITT':                                      # :241-250
+                aks = levels(sat_data.averaging_kernels, nz + 1)
+                pw = np.empty((1))
+            if sat_data.sensor == 'GOSAT':                                       # :251-268
+                aks = levels(sat_data.averaging_kernels, nz)
+                pw = levels(sat_data.pressure_weight, nz)
+            pm = levels(sat_data.pressure_mid, nz)                               # :270-277
+            apro = levels(sat_data.apriori_profile, nz)                          # :278-283
+            fields = (vcd, sat_data.time, [], trop, uy, ux, [], [], unc, [], pm, aks, need, [], [], [],
+                      single["aprior_column"], apro, single["surface_pressure"], single["apriori_surface"], x_col, pw,
+                      sat_data.sensor)                                           # :285-287
+            return record_type(*fields) if record_type is not None else fields
         # per-level cubes of the two-step retrievals, interpolator.py:191-213
         if np.size(sat_data.scattering_weights) != 1:
             nz = np.shape(sat_data.pressure_mid)[0]

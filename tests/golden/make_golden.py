@@ -242,6 +242,39 @@ def gen_interpolator_rbf():
     save("interpolator_rbf.npz", **out)
 
 
+def gen_interpolator_levels():
+    """interpolator() on records that carry per-level cubes: the satellite_amf scattering-weight / pressure loops
+    (interpolator.py:191-213) and both satellite_opt branches -- MOPITT (nz+1 averaging-kernel rows, no pressure weights)
+    and GOSAT (nz rows + pressure weights) -- incl. a-priori column / surface, surface pressure, x_col, a-priori profile
+    (:216-283) and the positional rebuild (:284-290).  Types 4 (k-d tree) and 1 (Delaunay), a coarse model grid (box
+    filter + NN pick) and a fine one (pass-through to the 0.25 deg grid)."""
+    out = {}
+    grids = {"coarse": (-6.0, 26.0, 2.0, 18.0, 2.0, 2.5, 0.25), "fine": (4.0, 16.0, 6.0, 14.0, 0.25, 0.25, 0.25)}
+    for kind, seed in (("amf", 6101), ("MOPITT", 6102), ("GOSAT", 6103)):
+        g = syn.swath_level_granule(seed, kind=kind, nz=3)
+        for f in dataclasses.fields(g):
+            v = getattr(g, f.name)
+            if isinstance(v, np.ndarray) and v.size > 1:
+                out[f"{kind}_in_{f.name}"] = v
+        for tag, (la0, la1, lo0, lo1, dlat, dlon, gs) in grids.items():
+            ctm = syn.regional_ctm_grid(la0, la1, lo0, lo1, dlat, dlon)
+            out[f"{tag}_clat"], out[f"{tag}_clon"], out[f"{tag}_gs"] = ctm["Latitude"], ctm["Longitude"], gs
+            for it in (4, 1):
+                r = quiet(REF_interp.interpolator, it, gs, to_ref(g), ctm, 0.75)
+                assert r is not None
+                names = []
+                for f in dataclasses.fields(r):
+                    v = getattr(r, f.name)
+                    if isinstance(v, np.ndarray):
+                        out[f"{kind}_{tag}_t{it}_{f.name}"] = v
+                        names.append(f.name)
+                    elif isinstance(v, (bool, str)):
+                        out[f"{kind}_{tag}_t{it}_{f.name}"] = np.array(v)
+                        names.append(f.name)
+                out[f"{kind}_{tag}_t{it}_arrays"] = np.array(names)
+    save("interpolator_levels.npz", **out)
+
+
 def amf_cases():
     """name -> (ctm_data, sat_data) builders shared with the tests (seeded)"""
     def case_a():
@@ -351,6 +384,9 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["akconv"]:
         gen_ak_conv()
         raise SystemExit(0)
+    if sys.argv[1:] == ["levels"]:
+        gen_interpolator_levels()
+        raise SystemExit(0)
     if sys.argv[1:] == ["pwv"]:
         gen_pwv()
         raise SystemExit(0)
@@ -364,6 +400,7 @@ if __name__ == "__main__":
     gen_upscaler()
     gen_interpolator()
     gen_interpolator_rbf()
+    gen_interpolator_levels()
     gen_amf_recal()
     gen_ak_conv()
     gen_pwv()

@@ -1,0 +1,364 @@
+"""Round-2 GPU parity and robustness tests (run with -m gpu on an MI355X).
+
+  * interpolator() on records with per-level cubes -- satellite_amf scattering weights (interpolator.py:191-213) and
+    the satellite_opt MOPITT / GOSAT branch (:216-291) -- against outputs of the reference's own function;
+  * the analysis modes of oisatgmi.oi() (driver.py:108-114) and the `scale` anchor of the dense analysis against the
+    reference's OI golden packs in the L -> 0 limit (optimal_interpolation.py:27);
+  * localised block-B at FULL size (BASELINE configs[2] as worded) and the HCHO / O3 parameter sets (configs[4]) at
+    full size, through size-independent properties;
+  * (month x tile) batches (configs[3]) and the status of unchecked asynchronous solves.
+
+Tolerances: float64 regridding vs the reference 1e-12; dense analysis 1e-5 of the field scale (BASELINE north star).
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oi_oracle as orc                       # the checker (tests only)
+from oisatgmi import _hip, synthetic as syn, config as cfg, dense
+from oisatgmi.interpolator import interpolator
+from oisatgmi.driver import oisatgmi
+import oisatgmi.optimal_interpolation as oi_mod
+from test_oracle_golden import level_granule_from_golden, check_level_record
+
+RT64 = 1e-12
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = _hip.context()
+    assert "gfx950" in c.device_info()["name"]
+    return c
+
+
+# ------------------------------------------------------------------------------------------------
+# interpolator(): 3-D loops and the satellite_opt branch, against the reference's outputs
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["amf", "MOPITT", "GOSAT"])
+def test_interpolator_level_cubes_match_reference(ctx, golden, kind):
+    g = golden("interpolator_levels.npz")
+    s = level_granule_from_golden(g, kind)
+    for tag in ("coarse", "fine"):
+        ctm = {"Latitude": g[f"{tag}_clat"], "Longitude": g[f"{tag}_clon"]}
+        for it in (4, 1):
+            r = interpolator(it, float(g[f"{tag}_gs"]), s, ctm, 0.75)
+            check_level_record(g, kind, tag, it, r, RT64)
+
+
+def test_interpolator_opt_record_edge_cases(ctx, golden):
+    """What the reference does with a satellite_opt record it cannot rebuild: an all-zero a-priori column leaves the name
+    unbound (interpolator.py:219,:285-287 -> NameError), and so does a sensor that is neither MOPITT nor GOSAT."""
+    g = golden("interpolator_levels.npz")
+    ctm = {"Latitude": g["coarse_clat"], "Longitude": g["coarse_clon"]}
+    s = syn.swath_level_granule(6102, kind="MOPITT", nz=3)
+    s.aprior_column = np.zeros_like(s.aprior_column)
+    with pytest.raises(NameError):
+        interpolator(4, 0.25, s, ctm, 0.75)
+    s = syn.swath_level_granule(6102, kind="MOPITT", nz=3)
+    s.sensor = "TES"
+    with pytest.raises(NameError):
+        interpolator(4, 0.25, s, ctm, 0.75)
+    # a tropopause array on a satellite_opt record is regridded like any other 2-D field (:174-180)
+    s = syn.swath_level_granule(6103, kind="GOSAT", nz=3)
+    s.tropopause = 200.0 + s.latitude_center
+    r = interpolator(4, 0.25, s, ctm, 0.75)
+    want = orc.interpolator(4, 0.25, s, ctm, 0.75, record_type=cfg.satellite_opt)
+    np.testing.assert_allclose(r.tropopause, want.tropopause, rtol=RT64, equal_nan=True)
+    np.testing.assert_allclose(r.pressure_weight, want.pressure_weight, rtol=RT64, equal_nan=True)
+
+
+# ------------------------------------------------------------------------------------------------
+# dense analysis: `scale` tied to the reference's regularisation factor; oi() modes
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("index", [7, 37, 98])
+def test_dense_scale_matches_reference_regularisation_in_the_limit(ctx, golden, index):
+    """OI_dense(scale = s) with L -> 0 and H = cell selection against the reference's OI(regularization_on=True) outputs
+    at the forced sweep indices: ties `scale` to `Sa*reg` of optimal_interpolation.py:27 (s = 0.8, 3.8, 9.9)."""
+    g = golden("oi_72x144.npz")
+    Xa, Y, Sa, So = g["Xa"].copy(), g["Y"].copy(), g["Sa"].copy(), g["So"].copy()
+    lat, lon = syn.global_grid(72, 144)
+    s = float(oi_mod.scaling_factors(True)[index])
+    assert s == float(g["curve_x"][index])
+    ok = np.isfinite(Y) & np.isfinite(So) & np.isfinite(Xa) & np.isfinite(Sa)
+    xb, inc, info = dense.OI_dense(Xa, Y.copy(), Sa, So, lat, lon, L_km=1e-3, scale=s, refine=1, dtype=np.float64, want_error=True)
+    want = {k: g[f"on{index}_{k}"].reshape(72, 144) for k in ("Xb", "AK", "inc", "err")}
+    fs = np.nanmax(np.abs(want["Xb"]))
+    assert np.abs(xb[ok] - want["Xb"][ok]).max() <= 1e-6 * fs
+    assert np.abs(inc[ok] - want["inc"][ok]).max() <= 1e-6 * fs
+    pos = ok & (Sa > 0)
+    np.testing.assert_allclose(info["ak"][pos], want["AK"][pos], atol=2e-6, rtol=0)
+    np.testing.assert_allclose(info["err"][pos], want["err"][pos], rtol=2e-3, atol=1e-4)
+
+
+class _Reader:
+    pass
+
+
+def _facade_from_golden(g):
+    Xa, Y, Sa, So = g["Xa"].copy(), g["Y"].copy(), g["Sa"].copy(), g["So"].copy()
+    o = oisatgmi()
+    o.ctm_averaged_vcd = Xa
+    o.sat_averaged_vcd = Y
+    o.sat_averaged_error = np.sqrt(So)
+    o.aux1, o.aux2 = Y.copy(), Xa.copy()
+    # error_ctm that reproduces the golden Sa = (0.5 Xa)^2 (Sa of the special cells is restored below)
+    lat, lon = syn.global_grid(72, 144)
+    o.grid_lat, o.grid_lon = lat, lon
+    return o, Xa, Y, Sa, So
+
+
+@pytest.mark.parametrize("mode", ["dense", "tiled"])
+def test_oi_modes_reduce_to_the_reference_attributes(ctx, golden, mode, monkeypatch):
+    """oisatgmi.oi(sensor, error_ctm) in `dense` / `tiled` mode (selected by environment, the signature is untouched)
+    with L -> 0: the four attributes driver.py:110-114 sets equal the reference's OI outputs at observed cells, NaN
+    elsewhere (OISAT_UNOBSERVED=nan, the default) -- with the knee index forced as in the golden packs."""
+    g = golden("oi_72x144.npz")
+    o, Xa, Y, Sa, So = _facade_from_golden(g)
+    # the golden Sa is (0.5 Xa)^2 except at two doctored cells; drive oi() with error_ctm = 50 and compare away from them
+    doctored = ~np.isclose(Sa, (Xa * 0.5) ** 2, rtol=1e-12, equal_nan=True) | ~np.isfinite(Sa)
+    monkeypatch.setenv("OISAT_OI_MODE", mode)
+    monkeypatch.setenv("OISAT_CORR_LENGTH_KM", "0.001")
+    monkeypatch.setenv("OISAT_TILE_DEG", "45")
+    o.oi_reg_index = 37
+    o.oi("OMI", error_ctm=50.0)
+    assert o.oi_info["mode"] == mode and o.oi_info["reg_index"] == 37 and o.oi_info["scale"] == float(g["curve_x"][37])
+    want = {k: g[f"on37_{k}"].reshape(72, 144) for k in ("Xb", "AK", "inc", "err")}
+    ok = np.isfinite(Y) & np.isfinite(So) & np.isfinite(Xa) & ~doctored
+    fs = np.nanmax(np.abs(want["Xb"]))
+    assert np.abs(o.ctm_averaged_vcd_corrected[ok] - want["Xb"][ok]).max() <= 1e-6 * fs
+    assert np.abs(o.increment_OI[ok] - want["inc"][ok]).max() <= 1e-6 * fs
+    np.testing.assert_allclose(o.ak_OI[ok], want["AK"][ok], atol=2e-6, rtol=0)
+    np.testing.assert_allclose(o.error_OI[ok], want["err"][ok], rtol=2e-3, atol=1e-4)
+    un = ~(np.isfinite(Y) & ~np.isnan(So) & np.isfinite(Xa) & np.isfinite(Sa))
+    # the three doctored cells of the golden month behave as in the reference: So = inf -> K = 0 (Xb = Xa, AK = 0,
+    # err = prior); Xa = NaN -> NaN; (Sa = 0 is not reproducible through error_ctm and is skipped)
+    (i0, j0), (i1, j1), (i2, j2) = np.argwhere(~np.isnan(g["Y"]))[:3]
+    assert np.isinf(So[i1, j1]) and o.ak_OI[i1, j1] == 0.0 and o.ctm_averaged_vcd_corrected[i1, j1] == Xa[i1, j1]
+    np.testing.assert_allclose(o.error_OI[i1, j1], want["err"][i1, j1], rtol=1e-6)
+    assert np.isnan(o.ctm_averaged_vcd_corrected[i2, j2])
+    for a in (o.ctm_averaged_vcd_corrected, o.increment_OI, o.ak_OI, o.error_OI):
+        assert np.isnan(a[un]).all() and a.shape == (72, 144) and a.dtype == np.float64
+    assert (o.sat_averaged_vcd[np.isfinite(o.sat_averaged_vcd)] >= 0).all()         # the in-place clamp (:14)
+    # the other convention: unobserved cells keep the background, the prior error and a zero averaging kernel
+    o2, Xa2, *_ = _facade_from_golden(g)
+    o2.oi_reg_index = 37
+    o2.oi_unobserved = "xa"
+    o2.oi("OMI", error_ctm=50.0)
+    free = un & np.isfinite(Xa2)
+    np.testing.assert_array_equal(o2.ctm_averaged_vcd_corrected[free], Xa2[free])
+    np.testing.assert_array_equal(o2.ak_OI[free], 0.0)
+    np.testing.assert_allclose(o2.error_OI[free], np.sqrt(3.8) * 0.5 * np.abs(Xa2[free]), rtol=1e-6)
+    # default mode is the reference's element-wise analysis, bit for bit the OI() call
+    monkeypatch.delenv("OISAT_OI_MODE")
+    o3, *_ = _facade_from_golden(g)
+    o3.oi_reg_index = 37
+    o3.oi("OMI", error_ctm=50.0)
+    np.testing.assert_allclose(o3.ctm_averaged_vcd_corrected[ok], want["Xb"][ok], rtol=RT64)
+    monkeypatch.setenv("OISAT_OI_MODE", "banana")
+    with pytest.raises(ValueError):
+        o3.oi("OMI")
+
+
+def test_oi_dense_mode_spreads_increments(ctx):
+    """Away from the limit: `dense` mode through the facade equals OI_dense with the knee-picked scale, and with
+    OISAT_UNOBSERVED=xa unobserved cells receive the spread increment (checked against the float64 oracle)."""
+    c = syn.diag_case(36, 72, 400, 77)
+    lat, lon = syn.global_grid(36, 72)
+    o = oisatgmi()
+    o.ctm_averaged_vcd, o.sat_averaged_vcd = c.Xa.copy(), c.Y.copy()
+    o.sat_averaged_error = np.sqrt(c.So)
+    o.grid_lat, o.grid_lon = lat, lon
+    o.oi_mode, o.corr_length_km, o.oi_unobserved = "dense", 600.0, "xa"
+    o.oi("OMI", error_ctm=50.0)
+    s = o.oi_info["scale"]
+    Y = np.where(c.Y < 0, 0.0, c.Y)
+    ok = np.isfinite(Y)
+    cell = np.flatnonzero(ok.ravel())
+    ref = orc.dense_oi(lat, lon, c.Xa, s * (0.5 * c.Xa) ** 2, lat.ravel()[cell], lon.ravel()[cell], cell, Y.ravel()[cell],
+                       c.So.ravel()[cell], 600.0)
+    fs = np.abs(c.Xa).max()
+    assert np.abs(o.ctm_averaged_vcd_corrected.ravel() - ref["xa"]).max() <= 1e-5 * fs
+    assert np.abs(o.increment_OI[~ok]).max() > 1e-3 * fs                       # information really spreads
+
+
+# ------------------------------------------------------------------------------------------------
+# full-size checks (BASELINE configs[2] as worded, configs[4])
+# ------------------------------------------------------------------------------------------------
+def test_tiled_config3_full_size_properties(ctx):
+    """Localised block-B at FULL size: 720x1440 grid, ~1e5 swath observations, 72 tiles of 30 deg with a 3 L halo, twelve
+    lanes.  Per tile (every tile): float64 residual of (H B H^T + R) z = d on random rows and the increment B H^T z on
+    random cells, both re-derived on the host from the oracle's covariance formula with the tile's own observation set."""
+    L = 300.0
+    p = syn.point_obs_case(720, 1440, 100000, 4000, swaths=True)
+    cell = dense.regular_grid_cell(p.lat, p.lon, p.obs_lat, p.obs_lon)
+    y = np.where(p.obs_y < 0, 0, p.obs_y)
+    ta = dense.TiledAnalysis(p.lat, p.lon, tile_deg=30.0, halo_km=3.0 * L, dtype=np.float32)
+    ta.load(p.Xa, p.Sa, p.obs_lat, p.obs_lon, p.obs_y, p.obs_var)
+    assert len(ta.tiles) == 72 and all(t["obs"].size > 1000 for t in ta.tiles)
+    ta.run(L, refine=2, check_pd=True)
+    xa, inc = ta.download()
+    assert np.isfinite(xa).all() and np.isfinite(inc).all()
+    sb = np.sqrt(p.Sa.ravel())
+    d_all = y - p.Xa.ravel()[cell]
+    scale = np.abs(p.Xa).max()
+    nx = 1440
+    rng = np.random.default_rng(31)
+    worst_r, worst_i = 0.0, 0.0
+    for ti, (t, plan) in enumerate(zip(ta.tiles, ta.plans)):
+        o = t["obs"]
+        z = plan.download_z()
+        assert np.isfinite(z).all()
+        po = orc.unit_vectors(p.obs_lat[o], p.obs_lon[o])
+        so = sb[cell[o]]
+        rows = rng.choice(o.size, 24, replace=False)
+        Srows = orc.gaussian_corr(po[rows], po, L) * so[rows][:, None] * so[None, :]
+        r = d_all[o][rows] - (Srows @ z + p.obs_var[o][rows] * z[rows])
+        worst_r = max(worst_r, np.abs(r).max() / np.abs(d_all[o]).max())
+        (y0, y1), (x0, x1) = t["rows"], t["cols"]
+        iy, ix = rng.integers(y0, y1, 40), rng.integers(x0, x1, 40)
+        cells = iy * nx + ix
+        pg = orc.unit_vectors(p.lat.ravel()[cells], p.lon.ravel()[cells])
+        inc_ref = sb[cells] * (orc.gaussian_corr(pg, po, L) @ (so * z))
+        worst_i = max(worst_i, np.abs(inc.ravel()[cells] - inc_ref).max() / scale)
+        assert np.abs(xa.ravel()[cells] - (p.Xa.ravel()[cells] + inc_ref)).max() <= 1e-5 * scale, ti
+    assert worst_r <= 1e-6, worst_r
+    assert worst_i <= 1e-5, worst_i
+    assert np.abs(xa.ravel()[cell] - y).mean() < 0.8 * np.abs(p.Xa.ravel()[cell] - y).mean()
+    ta.pool.close()
+
+
+@pytest.mark.parametrize("species", ["HCHO", "O3"])
+def test_dense_config5_full_size_properties(ctx, species):
+    """BASELINE configs[4]: the HCHO and O3 parameter sets (control_omihcho.yml / control_omio3.yml shapes: value ranges,
+    ctm_error, observation-error model) at FULL size -- same size-independent properties as the NO2 full-size test."""
+    p = syn.point_obs_case(720, 1440, 100000, 5005, swaths=True, species=species)
+    cell = dense.regular_grid_cell(p.lat, p.lon, p.obs_lat, p.obs_lon)
+    L = 300.0
+    y = np.where(p.obs_y < 0, 0, p.obs_y)
+    m = int(y.size)
+    plan = dense.DenseAnalysis(p.lat, p.lon, max_obs=m, dtype=np.float32)
+    plan.load_background(p.Xa, p.Sa)
+    plan.load_obs(p.obs_lat, p.obs_lon, cell, y, p.obs_var)
+    resid = plan.run(L, refine=2, check_pd=True, want_resid=True)
+    assert resid[-1] < 1e-7 and resid[-1] < resid[0], resid
+    xa, inc = plan.download()
+    z = plan.download_z()
+    del plan
+    assert np.isfinite(z).all() and np.isfinite(xa).all()
+    sb = np.sqrt(p.Sa.ravel())
+    po = orc.unit_vectors(p.obs_lat, p.obs_lon)
+    d = y - p.Xa.astype(np.float32).ravel()[cell].astype(np.float64)
+    rows = np.random.default_rng(9).choice(m, 96, replace=False)
+    Srows = orc.gaussian_corr(po[rows], po, L) * sb[cell][rows][:, None] * sb[cell][None, :]
+    r = d[rows] - (Srows @ z + p.obs_var[rows] * z[rows])
+    assert np.abs(r).max() <= 1e-6 * np.abs(d).max(), np.abs(r).max() / np.abs(d).max()
+    sel = np.random.default_rng(10).choice(p.Xa.size, 1500, replace=False)
+    pg = orc.unit_vectors(p.lat.ravel()[sel], p.lon.ravel()[sel])
+    inc_ref = sb[sel] * (orc.gaussian_corr(pg, po, L) @ (sb[cell] * z))
+    scale = np.abs(p.Xa).max()
+    assert np.abs(inc.ravel()[sel] - inc_ref).max() <= 1e-5 * scale
+    assert np.abs(xa.ravel()[sel] - (p.Xa.ravel()[sel] + inc_ref)).max() <= 1e-5 * scale
+
+
+# ------------------------------------------------------------------------------------------------
+# (month x tile) batches and unchecked asynchronous solves
+# ------------------------------------------------------------------------------------------------
+def test_month_tile_batch_equals_per_month_tiled_analysis(ctx):
+    """A batch holding an arbitrary subset of the (month x tile) units of three months writes, for every unit it owns,
+    exactly the tile the month's own TiledAnalysis produces (bitwise: the lane a tile runs on does not matter)."""
+    ny, nx, L = 36, 72, 400.0
+    lat, lon = syn.global_grid(ny, nx)
+    months = {k: syn.point_obs_case(ny, nx, 700 + 100 * k, 8100 + k) for k in range(3)}
+    owned = {0: [0, 3, 4, 17], 1: [5], 2: [1, 2, 9, 10, 11]}
+    batch = dense.MonthTileBatch(lat, lon, tile_deg=60.0, halo_km=3 * L, dtype=np.float32, streams=4)
+    for k, p in months.items():
+        batch.add_month(k, p.Xa, p.Sa, p.obs_lat, p.obs_lon, p.obs_y, p.obs_var, only=owned[k])
+    batch.build()
+    assert sorted((k, ti) for k, ti, _ in batch.units) == sorted((k, ti) for k, v in owned.items() for ti in v)
+    batch.run(L, refine=2, check_pd=True)
+    slab = batch.download_slab()
+    for k, p in months.items():
+        ta = dense.TiledAnalysis(lat, lon, tile_deg=60.0, halo_km=3 * L, dtype=np.float32, streams=3)
+        ta.load(p.Xa, p.Sa, p.obs_lat, p.obs_lon, p.obs_y, p.obs_var)
+        ta.run(L, refine=2)
+        xa, inc = ta.download()
+        ta.pool.close()
+        for u, (key, ti, _) in enumerate(batch.units):
+            if key != k:
+                continue
+            (y0, y1), (x0, x1) = ta.tiles[ti]["rows"], ta.tiles[ti]["cols"]
+            shape = batch.unit_shape(u)
+            got = slab[batch.offsets[u]: batch.offsets[u] + int(np.prod(shape))].reshape(shape)
+            np.testing.assert_array_equal(got[0], xa[y0:y1, x0:x1])
+            np.testing.assert_array_equal(got[1], inc[y0:y1, x0:x1])
+    batch.close()
+
+
+def test_unchecked_runs_cannot_fail_silently(ctx):
+    """VERDICT r1 / ADVICE: run() is asynchronous and unchecked by default; a non-positive pivot (or a triangular-solve
+    time-out) must surface at the next download / check instead of handing back garbage."""
+    p = syn.point_obs_case(36, 72, 300, 1300)
+    cell = dense.regular_grid_cell(p.lat, p.lon, p.obs_lat, p.obs_lon)
+    y = np.where(p.obs_y < 0, 0, p.obs_y)
+    plan = dense.DenseAnalysis(p.lat, p.lon, max_obs=300, dtype=np.float32)
+    plan.load_background(p.Xa, p.Sa)
+    bad_var = p.obs_var.copy()
+    bad_var[137] = -1e6                                   # S[137][137] < 0: not positive definite
+    plan.load_obs(p.obs_lat, p.obs_lon, cell, y, bad_var)
+    plan.run(600.0, refine=1)                             # unchecked: returns at once
+    with pytest.raises(_hip.OisatError, match="not positive definite"):
+        plan.download()
+    assert plan.ctx.solve_status() == (0, 0, 0)           # the failure was reported once and cleared
+    with pytest.raises(_hip.OisatError):                  # the checked form still reports its own factorization
+        plan.run(600.0, refine=1, check_pd=True)
+    plan.ctx.solve_status(clear=True)
+    plan.load_obs(p.obs_lat, p.obs_lon, cell, y, p.obs_var)
+    plan.run(600.0, refine=1)
+    xa, _ = plan.download()                               # a good run after a bad one passes
+    assert np.isfinite(xa).all()
+    # the same through the lanes of a tiled analysis: one bad tile fails the month
+    ta = dense.TiledAnalysis(p.lat, p.lon, tile_deg=90.0, halo_km=1500.0, dtype=np.float32, streams=3)
+    ta.load(p.Xa, p.Sa, p.obs_lat, p.obs_lon, p.obs_y, bad_var)
+    with pytest.raises(_hip.OisatError, match="not positive definite"):
+        ta.run(500.0, refine=1)
+    ta.load(p.Xa, p.Sa, p.obs_lat, p.obs_lon, p.obs_y, p.obs_var)
+    ta.run(500.0, refine=1)
+    ta.pool.close()
+
+
+def test_gain_diag_aggregates_observations_that_share_a_cell(ctx):
+    """OI_dense(want_error=True) with several observations in one grid cell: the cell's averaging kernel is the SUM of
+    diag(H K) over its observations (= diag(K H) at the cell), independent of their order."""
+    p = syn.point_obs_case(18, 36, 500, 4242)              # 648 cells, 500 scattered observations: many shared cells
+    cell = dense.regular_grid_cell(p.lat, p.lon, p.obs_lat, p.obs_lon)
+    assert np.unique(cell).size < cell.size
+    obs = dict(lat=p.obs_lat, lon=p.obs_lon, y=p.obs_y, var=p.obs_var)
+    _, _, a = dense.OI_dense(p.Xa, None, p.Sa, None, p.lat, p.lon, 800.0, dtype=np.float32, want_error=True, obs=obs)
+    perm = np.random.default_rng(0).permutation(cell.size)
+    obs2 = {k: v[perm] for k, v in obs.items()}
+    _, _, b = dense.OI_dense(p.Xa, None, p.Sa, None, p.lat, p.lon, 800.0, dtype=np.float32, want_error=True, obs=obs2)
+    np.testing.assert_allclose(a["ak"], b["ak"], rtol=0, atol=1e-12, equal_nan=True)
+    ref = orc.dense_oi(p.lat, p.lon, p.Xa, p.Sa, p.obs_lat, p.obs_lon, cell, np.where(p.obs_y < 0, 0, p.obs_y), p.obs_var, 800.0,
+                       want_error=True)
+    want = np.zeros(p.Xa.size)
+    np.add.at(want, cell, ref["ak_obs"])
+    got = a["ak"].ravel()
+    np.testing.assert_allclose(got[np.unique(cell)], want[np.unique(cell)], atol=5e-5, rtol=0)
+    assert np.isnan(np.delete(got, np.unique(cell))).all()
+
+
+def test_averaging_promotes_mixed_dtype_stacks_like_numpy(ctx):
+    """float32 and float64 granules in one month -> np.array(list) promotes the stack to float64."""
+    from oisatgmi.averaging import averaging
+    r = _Reader()
+    r.sat_data = syn.granule_stack(24, 40, 6, 556)
+    live = [g for g in r.sat_data if g is not None]
+    for f in ("vcd", "uncertainty", "ctm_vcd", "new_amf", "old_amf"):
+        setattr(live[0], f, getattr(live[0], f).astype(np.float32))          # the FIRST granule is float32, the rest float64
+    res = averaging("2019-06-01", "2019-07-01", r)
+    ref = orc.averaging("2019-06-01", "2019-07-01", r, amf_type=cfg.satellite_amf, opt_type=cfg.satellite_opt)
+    for a, b in zip(res[:5], ref[:5]):
+        np.testing.assert_allclose(a, b, rtol=RT64, equal_nan=True)

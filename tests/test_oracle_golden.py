@@ -119,6 +119,53 @@ def test_interpolator(golden):
     assert bool(g["miss_is_none"])
 
 
+LEVEL_KINDS = {"amf": 6101, "MOPITT": 6102, "GOSAT": 6103}
+
+
+def level_granule_from_golden(g, kind):
+    """the seeded swath record, checked field by field against the inputs stored with the reference's outputs"""
+    s = syn.swath_level_granule(LEVEL_KINDS[kind], kind=kind, nz=3)
+    for f in dataclasses.fields(s):
+        v = getattr(s, f.name)
+        if isinstance(v, np.ndarray) and v.size > 1:
+            np.testing.assert_array_equal(v, g[f"{kind}_in_{f.name}"])
+    return s
+
+
+def check_level_record(g, kind, tag, it, r, rtol):
+    """every array / flag the reference's interpolator() returned for this record kind"""
+    want_type = cfg.satellite_amf if kind == "amf" else cfg.satellite_opt
+    assert isinstance(r, want_type)
+    for name in g[f"{kind}_{tag}_t{it}_arrays"]:
+        want = g[f"{kind}_{tag}_t{it}_{name}"]
+        got = getattr(r, str(name))
+        if want.dtype.kind in "bU":
+            assert got == want.item(), (kind, tag, it, name)
+        elif want.shape == (1,):                     # np.empty((1)) placeholders: shape only (:180, :250)
+            assert np.shape(got) == (1,), (kind, tag, it, name)
+        else:
+            assert np.shape(got) == want.shape, (kind, tag, it, name, np.shape(got), want.shape)
+            np.testing.assert_allclose(np.asarray(got), want, rtol=rtol, equal_nan=True, err_msg=f"{kind} {tag} type {it} {name}")
+    for name in ("profile", "latitude_corner", "longitude_corner", "quality_flag", "ctm_vcd", "ctm_time_at_sat"):
+        if hasattr(r, name):
+            assert getattr(r, name) == [], name      # positional [] slots of the rebuild (:285-290)
+    assert r.time == datetime.datetime(2019, 6, 15, 13, 45)
+
+
+@pytest.mark.parametrize("kind", ["amf", "MOPITT", "GOSAT"])
+def test_interpolator_level_cubes(golden, kind):
+    """3-D loops of interpolator(): scattering weights / pressure (satellite_amf, interpolator.py:191-213) and the
+    satellite_opt branch (MOPITT, GOSAT; :216-291), against the reference's own outputs."""
+    g = golden("interpolator_levels.npz")
+    s = level_granule_from_golden(g, kind)
+    rt = cfg.satellite_amf if kind == "amf" else cfg.satellite_opt
+    for tag in ("coarse", "fine"):
+        ctm = {"Latitude": g[f"{tag}_clat"], "Longitude": g[f"{tag}_clon"]}
+        for it in (4, 1):
+            r = orc.interpolator(it, float(g[f"{tag}_gs"]), s, ctm, 0.75, record_type=rt)
+            check_level_record(g, kind, tag, it, r, 1e-12)
+
+
 def test_interpolator_type3_rbf(golden):
     """RBFInterpolator(neighbors=5) restatement against the reference's own type-3 outputs."""
     g = golden("interpolator_rbf.npz")
