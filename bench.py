@@ -176,6 +176,110 @@ def tier_a_leg(ctx, ny, nx, nobs, sync):
                                           "8 B/cell read once = %.1f GB/s" % (8.0 * n / (curve_ms * 1e-3) / 1e9)}}
 
 
+def _hbm(bytes_, ms):
+    gbs = bytes_ / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "algorithmic_bytes": int(bytes_), "kernel_ms": ms}
+
+
+def _prof_mean(ctx, fn, reps):
+    """mean duration per launch (ms) of every kernel `fn` enqueues, from HIP events on the launch stream"""
+    fn()
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    for _ in range(reps):
+        fn()
+    prof = ctx.prof_collect()
+    ctx.prof_enable(False)
+    return {k: v["total_ms"] / v["launches"] for k, v in prof.items()}
+
+
+def tier_a_kernels_leg(ctx, sync):
+    """HBM rooflines of the reference-parity (Tier-A) kernels at the sizes SURVEY section 8(d) names, device-resident,
+    float32 AND float64 (the reference's arithmetic is float64): monthly averaging of a 30-granule 720x1440 stack
+    (stack_reduce_kernel: nanmean and error_averager, (k+1) elements per cell), the element-wise OI analysis (8 per cell),
+    _upscaler's box-filter + pick (10x10 window on the 0.25 deg grid -> 2.5 deg model grid) and the nearest-neighbour
+    query of a 98,640-pixel granule onto the 0.25 deg global grid."""
+    from oisatgmi import _hip, synthetic as syn
+    from oisatgmi.optimal_interpolation import DiagOI
+    from oisatgmi.interpolator import NNIndex, _UpscalePlan
+    ny, nx, k = 720, 1440, 30
+    n = ny * nx
+    rng = np.random.default_rng(12)
+    out = {"sizes": {"grid": [ny, nx], "granules": k}}
+    host = rng.uniform(0.1, 5.0, size=(k, n)).astype(np.float32)
+    host[rng.uniform(size=host.shape) < 0.3] = np.nan
+    for dt, tag in ((np.float32, "f32"), (np.float64, "f64")):
+        dt = np.dtype(dt)
+        code, item = _hip.dtype_code(dt), dt.itemsize
+        stack = ctx.upload(host, dtype=dt)
+        res = ctx.alloc(n * item)
+        t = _prof_mean(ctx, lambda: (ctx.check(ctx.lib.oisat_nanmean_stack(ctx.h, code, stack.ptr, k, n, 1, res.ptr)),
+                                     ctx.check(ctx.lib.oisat_error_average(ctx.h, code, stack.ptr, k, n, 1, res.ptr))), 10)
+        out[f"nanmean_stack_{tag}"] = _hbm((k + 1) * n * item, t["nanmean_stack"])
+        out[f"error_average_{tag}"] = _hbm((k + 1) * n * item, t["error_average"])
+        stack.free()
+        # element-wise OI, analysis kernel + the whole fused call
+        c = syn.diag_case(ny, nx, 100000, 3001)
+        d = DiagOI(n, dtype=dt, ctx=ctx)
+        d.load(c.Xa, c.Y, c.Sa, c.So)
+        t = _prof_mean(ctx, lambda: d.run_fused(True), 10)
+        el = time_steps(lambda: d.run_fused(True), 30, 3, sync)
+        out[f"oi_apply_{tag}"] = _hbm(8 * n * item, t["oi_apply"])
+        out[f"oi_fused_{tag}"] = {"ms_per_call": 1e3 * el / 30, "value": n * 30 / el, "unit": "grid-cells/s",
+                                  "oi_curve_ms": t["oi_curve"], "oi_curve_read_GBs": 2 * n * item / (t["oi_curve"] * 1e-3) / 1e9}
+        # _upscaler: 10 x 10 box filter evaluated at the fine nodes the 72 x 144 model cells pick, 8 stacked fields
+        fine_lat, fine_lon = syn.global_grid(ny, nx)
+        ctm = syn.regional_ctm_grid(-88.75, 88.75, -178.75, 178.75, 2.5, 2.5)
+        plan = _UpscalePlan(fine_lon, fine_lat, ctm, 0.25, float(np.hypot(2.5, 2.5)))
+        nf = 8
+        fine = ctx.upload(rng.uniform(0.0, 1.0, size=(nf, n)), dtype=dt)
+        t = _prof_mean(ctx, lambda: plan.run(fine, nf, dt, False), 10)
+        out[f"boxfilter_pick_{tag}"] = _hbm(nf * plan.T * (plan.kx * plan.ky + 1) * item, t["boxfilter_pick"])
+        out[f"boxfilter_pick_{tag}"]["window"] = [plan.ky, plan.kx]
+        out[f"boxfilter_pick_{tag}"]["model_cells"] = plan.T
+        fine.free()
+    # nearest-neighbour query (coordinates are always double): count / scan / scatter / query passes over the point hash
+    g, ctm = _regrid_granule()
+    nn = NNIndex(g.longitude_center, g.latitude_center)
+    lon2, lat2 = np.meshgrid(np.arange(-179.875, 179.876, 0.25), np.arange(-89.875, 89.876, 0.25))
+    T = lon2.size
+    tb = ctx.upload(np.concatenate([lon2.ravel(), lat2.ravel()]))
+    idx = ctx.alloc(T * 4)
+    t = _prof_mean(ctx, lambda: ctx.check(ctx.lib.oisat_nn_query(ctx.h, nn.buf.at(0), nn.buf.at(nn.P * 8), nn.P, tb.at(0),
+                                                                 tb.at(T * 8), T, 0.5, idx.ptr, None)), 10)
+    total = sum(v for kname, v in t.items() if kname.startswith("nn_"))
+    out["nn_query_f64"] = _hbm(16 * nn.P + 16 * T + 4 * T, total)
+    out["nn_query_f64"].update(points=nn.P, targets=T, passes_ms=t,
+                               note="bytes = point + target coordinates (double lon/lat) read once + int32 index written; the "
+                                    "query pass walks the uniform-cell hash (L2-resident), so this is a latency/L2-bound kernel")
+    return out
+
+
+def pcie_leg(sync):
+    """The drop-in NumPy surface, host arrays in / host arrays out (PCIe-inclusive; never `value`)."""
+    import contextlib, io
+    from oisatgmi import synthetic as syn
+    from oisatgmi.optimal_interpolation import OI
+    from oisatgmi.averaging import error_averager
+    c = syn.diag_case(720, 1440, 100000, 3001)
+    out = {}
+    for dt, tag in ((np.float64, "f64"), (np.float32, "f32")):
+        a = [x.astype(dt) for x in (c.Xa, c.Y, c.Sa, c.So)]
+        with contextlib.redirect_stdout(io.StringIO()):
+            OI(a[0], a[1].copy(), a[2], a[3], True)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                OI(a[0], a[1].copy(), a[2], a[3], True)
+            out[f"OI_reg_on_720x1440_{tag}_ms"] = 1e3 * (time.perf_counter() - t0) / 5
+    e = np.random.default_rng(3).uniform(0.01, 1.0, size=(30, 720, 1440))
+    error_averager(e)
+    t0 = time.perf_counter()
+    error_averager(e)
+    out["error_averager_30x720x1440_f64_ms"] = 1e3 * (time.perf_counter() - t0)
+    return out
+
+
 def tiled_leg(ctx, workload, sync):
     """BASELINE configs[2] as worded: localised block-B -- 30 deg x 30 deg tiles, halo 3 L."""
     from oisatgmi import dense
@@ -229,14 +333,20 @@ def _regrid_granule():
 
 
 def cpu_baseline(workload):
-    """Time the float64 oracle (oracle/oi_oracle.py dense_oi: NumPy + SciPy Cholesky) on a bounded
-    sample of the workload -- the first `m_s` observations and a random subset of grid cells that
-    contains every observed cell -- sized for roughly 10-30 s of CPU work."""
+    """Time the float64 oracle (oracle/oi_oracle.py: NumPy + SciPy Cholesky, the CPU restatement of the reference's
+    algorithm) on the benchmark host, on BOUNDED samples of the workloads (about 10-30 s each):
+      * dense analysis: the first `m_s` observations (>= 25,000) of the config-3 month and a random subset of grid cells
+        that contains every observed cell; the Cholesky cost grows as m^3, so the full step (m = 1e5) is extrapolated;
+      * element-wise OI(regularization_on=True) at 720x1440 (the reference's own function; 16.7 s in BASELINE.md);
+      * error_averager on a 30x720x1440 stack (vectorised restatement; the reference's triple Python loop needs ~22 s);
+      * _upscaler 10x10 on the 0.25 deg grid; interpolator type 4 for three fields of the 98,640-pixel granule."""
     from oracle import oi_oracle as orc
+    import contextlib, io
     ny, nx, nobs, L, swaths, _ = WORKLOADS[workload]
     p, cell, _, _ = build_case(workload, 424242)
-    m_s = min(int(p.obs_y.size), 8000)
-    ncell_s = min(p.Xa.size, 65536)
+    m_full = int(p.obs_y.size)
+    m_s = min(m_full, 25000)
+    ncell_s = min(p.Xa.size, 32768)
     obs_cells = np.unique(cell[:m_s])
     rest = np.setdiff1d(np.random.default_rng(1).choice(p.Xa.size, ncell_s, replace=False), obs_cells)
     sel = np.concatenate([obs_cells, rest])[:max(ncell_s, obs_cells.size)]
@@ -246,27 +356,65 @@ def cpu_baseline(workload):
     orc.dense_oi(p.lat.ravel()[sel], p.lon.ravel()[sel], p.Xa.ravel()[sel], p.Sa.ravel()[sel], p.obs_lat[:m_s],
                  p.obs_lon[:m_s], lut[cell[:m_s]], np.where(p.obs_y[:m_s] < 0, 0, p.obs_y[:m_s]), p.obs_var[:m_s], L)
     dt = time.perf_counter() - t0
+    # the O(m^3) part by itself, to extrapolate: factor the same S again
+    import scipy.linalg as sla
+    po = orc.unit_vectors(p.obs_lat[:m_s], p.obs_lon[:m_s])
+    sb = np.sqrt(p.Sa.ravel())[cell[:m_s]]
+    S = orc.gaussian_corr(po, po, L) * sb[:, None] * sb[None, :]
+    S[np.diag_indices_from(S)] += p.obs_var[:m_s]
+    t1 = time.perf_counter()
+    sla.cho_factor(S, lower=True, overwrite_a=True, check_finite=False)
+    t_chol = time.perf_counter() - t1
+    del S
+    chol_tflops = m_s ** 3 / 3.0 / t_chol / 1e12
+    full_chol_s = (m_full / m_s) ** 3 * t_chol
     try:
         import threadpoolctl
         thr = max((i.get("num_threads", 1) for i in threadpoolctl.threadpool_info()), default=1)
     except Exception:
         thr = os.cpu_count() or 1
-    # the same oracle on the regridding row, for scale next to the "regrid" leg: it follows the reference's algorithm (one
-    # k-d tree build + query per field, interpolator.py:162-209); vcd, amf and uncertainty of the 98,640-pixel granule
-    import contextlib, io
+    out = {"value": sel.size / dt, "unit": "grid-cells/s", "cores": int(thr), "kind": "port",
+           "sample": f"oracle dense_oi (float64 NumPy/SciPy Cholesky, BLAS threads = cores) on {sel.size} cells x {m_s} obs "
+                     f"drawn from {workload} in {dt:.1f} s",
+           "dense_sample_seconds": dt, "cholesky_seconds_at_sample": t_chol, "cholesky_tflops_f64": chol_tflops,
+           "cholesky_seconds_extrapolated_to_full": full_chol_s,
+           "extrapolation": f"Cholesky cost ~ m^3: ({m_full}/{m_s})^3 x {t_chol:.2f} s = {full_chol_s:.0f} s for the factorization "
+                            f"of the full step alone (the GPU step is the whole analysis)",
+           "value_extrapolated_full_step": ny * nx / full_chol_s}
+    from oisatgmi import synthetic as syn
+    c = syn.diag_case(720, 1440, 100000, 3001)
+    with contextlib.redirect_stdout(io.StringIO()):
+        t0 = time.perf_counter()
+        orc.OI(c.Xa.copy(), c.Y.copy(), c.Sa, c.So, regularization_on=True)
+        out["OI_reg_on_720x1440_s"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        orc.OI(c.Xa.copy(), c.Y.copy(), c.Sa, c.So, regularization_on=False)
+        out["OI_reg_off_720x1440_s"] = time.perf_counter() - t0
+    e = np.random.default_rng(3).uniform(0.01, 1.0, size=(30, 720, 1440))
+    e[e < 0.3] = np.nan
+    t0 = time.perf_counter()
+    orc.error_averager(e)
+    out["error_averager_30x720x1440_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    np.nanmean(e, axis=0)
+    out["nanmean_30x720x1440_s"] = time.perf_counter() - t0
+    del e
+    fine_lat, fine_lon = syn.global_grid(720, 1440)
+    ctm10 = syn.regional_ctm_grid(-88.75, 88.75, -178.75, 178.75, 2.5, 2.5)
+    Z = np.random.default_rng(4).uniform(size=(720, 1440))
+    t0 = time.perf_counter()
+    orc.upscaler(fine_lon, fine_lat, Z, ctm10, 0.25, float(np.hypot(2.5, 2.5)))
+    out["upscaler_10x10_720x1440_s_per_field"] = time.perf_counter() - t0
+    # the regridding row: the oracle follows the reference's algorithm (one k-d tree build + query per field,
+    # interpolator.py:162-209); vcd, amf and uncertainty of the 98,640-pixel granule
     g, ctm = _regrid_granule()
     one = type(g)(g.vcd, g.amf, g.time, g.tropopause, g.latitude_center, g.longitude_center, [], [], g.uncertainty,
                   g.quality_flag, np.empty((1)), np.empty((1)), False, [], [], [], [])
     t1 = time.perf_counter()
     with contextlib.redirect_stdout(io.StringIO()):
         orc.interpolator(4, 0.25, one, ctm, 0.75, record_type=type(g))
-    regrid_s = time.perf_counter() - t1
-    return {"value": sel.size / dt, "unit": "grid-cells/s", "cores": int(thr), "kind": "port",
-            "regrid_type4_s_for_3_fields": regrid_s,
-            "sample": f"oracle dense_oi (float64 NumPy/SciPy Cholesky, BLAS threads = cores) on {sel.size} cells x {m_s} obs "
-                      f"drawn from {workload} in {dt:.1f} s; the full step has {ny*nx} cells x {int(p.obs_y.size)} obs and "
-                      f"its Cholesky cost grows as obs^3, so the CPU rate on the full step is far lower than this"}
-
+    out["regrid_type4_s_for_3_fields"] = time.perf_counter() - t1
+    return out
 
 def config4_leg(ctx, args, world, rank, local, lat2, lon2, sync, barrier):
     """BASELINE configs[3], STRONG scaling: a FIXED workload -- `c4_months` synthetic 720x1440 months of 10^5 swath
@@ -468,6 +616,8 @@ def main():
         if not args.no_secondary:
             out["tiled"] = tiled_leg(ctx, args.workload, sync)
             out["tier_a"] = tier_a_leg(ctx, ny, nx, nobs, sync)
+            out["tier_a_kernels"] = tier_a_kernels_leg(ctx, sync)
+            out["pcie_inclusive"] = pcie_leg(sync)
             out["regrid"] = regrid_leg(ctx, sync)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)

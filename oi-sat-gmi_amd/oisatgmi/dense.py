@@ -297,8 +297,16 @@ class LanePool:
             lane.sync()
 
     def check(self, what="tiled analysis"):
-        for lane in self.lanes:
-            lane.check_solves(what)
+        """Wait for every lane and read (and clear) every lane's solve status before raising, so that one failed unit
+        is reported once and does not poison the next run."""
+        errors = []
+        for li, lane in enumerate(self.lanes):
+            try:
+                lane.check_solves(f"{what}, lane {li}")
+            except _hip.OisatError as e:
+                errors.append(str(e))
+        if errors:
+            raise _hip.OisatError("; ".join(errors))
 
     def close(self):
         for f in self.factors:
