@@ -185,11 +185,15 @@ int oisat_gather_mask(oisat_ctx* h, int dtype, const void* values, int64_t P, in
  * host as in the reference (:153) and handed over as its arrays: simplices int32[ns][3], neighbors
  * int32[ns][3] (-1 = hull), transform double[ns][3][2] (scipy layout: Tinv rows, then the offset
  * vertex), vertex_to_simplex int32[P].  nn_idx: nearest swath pixel per target from oisat_nn_query
- * (-1: masked -> NaN); the point-location walk starts there.  Outside the hull -> NaN. */
+ * (-1: masked -> NaN); the point-location walk starts there.  Outside the hull -> NaN.  When the walk meets a
+ * degenerate simplex or does not converge it falls back, like scipy's _find_simplex_directed, to the brute-force scan
+ * (_find_simplex_bruteforce: bounding box, every simplex, eps_broad towards NaN-transform simplices).
+ * bounds_host: HOST double[4] = {min x, max x, min y, max y} of the triangulated points (Delaunay.min_bound /
+ * max_bound) for that scan's bounding-box test; NULL = no box test. */
 int oisat_linear_interp(oisat_ctx* h, int dtype, const double* tlon, const double* tlat, int64_t T,
                         const int32_t* nn_idx, const int32_t* vertex_to_simplex, const int32_t* simplices,
                         const int32_t* neighbors, const double* transform, int64_t nsimplex,
-                        const void* values, int64_t P, int nfields, void* out);
+                        const void* values, int64_t P, int nfields, void* out, const double* bounds_host);
 
 /* RBFInterpolator(points, values, neighbors=5)(targets) for nfields stacked fields (_interpolosis type 3,
  * interpolator.py:21-27): thin-plate-spline kernel, degree-1 polynomial tail, no smoothing; per target the

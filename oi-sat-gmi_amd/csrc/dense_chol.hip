@@ -314,53 +314,67 @@ __global__ __launch_bounds__(256) void gemm_nt_rows64_kernel(float* C, int64_t l
     }
 }
 
-// ---- diagonal block: Cholesky + inverse of one 128x128 block, one workgroup, all in LDS ----------
+// ---- diagonal block: Cholesky + inverse of one 128x128 block, one workgroup, ONE LDS image ------
 // Right-looking at 16-column granularity, 4 waves.  Per block column J:
 //   (1) wave 0 factors the 16x16 diagonal block in registers (lane = row, columns in VGPRs, pivots
-//       broadcast with v_readlane) and inverts it the same way;
+//       broadcast with v_readlane) and inverts it in the same sweep;
 //   (2) panel below:   P_I  = A[I,J] * Dinv_J^T          (v_mfma_f32_16x16x4_f32, 4 per 16x16 block)
 //   (3) trailing:      A[I,K] -= P_I * P_K^T,  J < K <= I
-// then T = L^-1 by doubling (16 -> 32 -> 64 -> 128):  T21 = -T22 * (L21 * T11), both products on
-// MFMA; the intermediate L21*T11 is parked in the unused upper triangle of the L image.
-// LDS: a[128][130] (L), t[128][130] (T), dinv[8][16][17].  Row stride 130 = 2 mod 32 keeps the
-// (row = lane&15, k = lane>>4) MFMA operand reads conflict-free.
+// then T = L^-1 by doubling (16 -> 32 -> 64 -> 128):  T21 = -T22 * (L21 * T11), both products on MFMA.
+//
+// LDS: a[128][130] floats and tdiag[128] -- 67,072 B, so the workgroup fits on a CU next to a 64 KB gemm_nt
+// workgroup (160 KB per CU).  Round 1 kept L and T in two images (137 KB): the kernel then needed an EMPTY CU, and in
+// any schedule that overlaps the diagonal chain with bulk updates it sat in the queue until a bulk launch drained
+// (300-350 us instead of 33).  Here the strictly upper triangle of the image -- free, L is lower -- holds T TRANSPOSED
+// (T[r][c], r > c, lives at a[c][r]) and tdiag holds T's diagonal; the inverse of each 16x16 diagonal block is written
+// straight to its final place by the wave that factors it.  The doubling step parks X = L21*T11 in the upper block
+// that T21^T will occupy: the T21 tiles are therefore held in registers across a barrier before they are written.
+// Row stride 130 floats: rows are 8-byte aligned, and 130 = 2 mod 32 spreads the (row = lane&15, k = lane>>4) MFMA
+// operand reads over the banks.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int LDA = 130;
-constexpr int DINV_LD = 17;
-constexpr int DINV_SZ = 16 * DINV_LD;
+constexpr size_t kDiagShm = sizeof(float) * (NB * LDA + NB);
 
 __device__ __forceinline__ float rdlane(float v, int l) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
 
-// Factor and invert in ONE sweep: column k of L is final after pivot step k, and that is exactly when the forward
-// substitution for X = L^-1 (lane = column r of X) needs it, so each broadcast L[c][k] = readlane(d[k], c) feeds both
-// the trailing update of the factor and the running sums of the inverse.  Half the serial broadcasts of doing the
-// two one after the other.
-__device__ __forceinline__ void diag16_factor_invert(float* a, int j0, float* dinvJ, int* info, int col0, int lane) {
+// element (k, j) of a lower-triangular inverse block whose strictly-lower part is stored transposed above the diagonal of
+// the image (origin o on the diagonal) and whose diagonal is in tdiag:  k > j: a[o+j][o+k];  k == j: tdiag;  k < j: 0
+__device__ __forceinline__ float tri_t(const float* a, const float* tdiag, int o, int k, int j) {
+    const float off = a[(o + (k > j ? j : k)) * LDA + o + (k > j ? k : j)];          // always an upper (or diagonal) address
+    return k > j ? off : (k == j ? tdiag[o + j] : 0.f);
+}
+
+// Factor and invert a 16x16 diagonal block in ONE sweep on one wave.  Lanes 0-15 hold the rows of the block
+// (v[c] = A[r][c]), lanes 16-31 the columns of the running inverse (v[c] = X[c][r], X = L^-1, starts as I): after pivot
+// step k column k of L is final, which is exactly what the forward substitution for X needs next, and BOTH updates
+// are the same instruction, v[c] -= v[k] * L[c][k] -- the factor's trailing update on lanes 0-15, the inverse's running
+// sums on lanes 16-31 -- with L[c][k] broadcast by v_readlane from lane c.  (Round 1 ran the two updates one after the
+// other on the same 16 lanes: twice the FMAs on the serial path.)
+__device__ __forceinline__ void diag16_factor_invert(float* a, float* tdiag, int j0, int* info, int col0, int lane) {
     const int r = lane & 15;
-    float d[16], x[16];
+    const bool inv = (lane & 16) != 0;                     // lanes 32-63 mirror 0-31 (never stored)
+    float v[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
-        d[c] = a[(j0 + r) * LDA + j0 + c];
-        x[c] = (c == r) ? 1.f : 0.f;                       // running delta_{c,r} - sum_{k<c} L[c][k] X[k][r]
+        const float dv = a[(j0 + r) * LDA + j0 + c];
+        v[c] = inv ? (c == r ? 1.f : 0.f) : dv;
     }
     int bad = 0;                                           // first non-positive / NaN pivot (wave-uniform), reported once below
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        float piv = rdlane(d[k], k);
+        float piv = rdlane(v[k], k);
         const bool neg = !(piv > 0.f);
         bad = (neg && bad == 0) ? k + 1 : bad;
         piv = neg ? 1.f : piv;
         float ri = __builtin_amdgcn_rsqf(piv);
         ri = ri * (1.5f - 0.5f * piv * ri * ri);          // one Newton step: ~0.5 ulp
-        d[k] = (r == k) ? piv * ri : d[k] * ri;
-        x[k] = (k >= r) ? x[k] * ri : 0.f;
+        v[k] = (!inv && r == k) ? piv * ri : v[k] * ri;   // L[k][k] = sqrt(piv); column k of L; X[k][:] /= L[k][k]
 #pragma unroll
         for (int c = k + 1; c < 16; ++c) {
-            const float l = rdlane(d[k], c);              // L[c][k]
-            d[c] -= d[k] * l;
-            x[c] -= l * x[k];
+            const float l = rdlane(v[k], c);              // L[c][k]  (lane c of the factor half)
+            v[c] -= v[k] * l;
         }
     }
     if (bad && lane == 0) {               // info[0]: this factorization; info[1], info[2]: sticky (first column, count)
@@ -368,26 +382,28 @@ __device__ __forceinline__ void diag16_factor_invert(float* a, int j0, float* di
         atomicCAS(info + 1, 0, col0 + bad);
         atomicAdd(info + 2, 1);
     }
+    if (lane < 16) {                      // L: lower part of row r (the upper part of the block now belongs to X^T)
 #pragma unroll
-    for (int c = 0; c < 16; ++c)
-        if (lane < 16) a[(j0 + r) * LDA + j0 + c] = (c <= r) ? d[c] : 0.f;
+        for (int c = 0; c < 16; ++c)
+            if (c <= r) a[(j0 + r) * LDA + j0 + c] = v[c];
+    } else if (lane < 32) {               // X[c][r], c > r, goes to its transposed place a[r][c]; X[r][r] to tdiag
 #pragma unroll
-    for (int rr = 0; rr < 16; ++rr)
-        if (lane < 16) dinvJ[rr * DINV_LD + r] = x[rr];
+        for (int c = 0; c < 16; ++c)
+            if (c > r) a[(j0 + r) * LDA + j0 + c] = v[c];
+        tdiag[j0 + r] = v[r];
+    }
 }
 
 __global__ __launch_bounds__(256) void potrf_diag_kernel(float* __restrict__ S, int64_t ld, int64_t k0, float* __restrict__ tinv,
                                                           int* __restrict__ info, int block_index) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* a = sm;                         // [128][LDA]
-    float* t = sm + NB * LDA;              // [128][LDA]
-    float* dinv = t + NB * LDA;            // [8][16][17]
+    float* a = sm;                         // [128][LDA]: L below/on the diagonal, T^T above it
+    float* tdiag = sm + NB * LDA;          // [128]: diagonal of T
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int lr = lane & 15, lg = lane >> 4;
     float* Sb = S + k0 * ld + k0;
     {   // 16 independent 16-byte loads per thread, issued together (row = (tid>>5)+8p, 4 columns at (tid&31)*4).
         // Row stride 130 floats keeps (r, c) with c % 4 == 0 8-byte aligned: two ds_write_b64 per quad.
-        // (t needs no clearing: every element of it that is read later has been written by then.)
         float4 v[16];
 #pragma unroll
         for (int p = 0; p < 16; ++p) v[p] = *reinterpret_cast<const float4*>(Sb + (int64_t)((tid >> 5) + 8 * p) * ld + (tid & 31) * 4);
@@ -403,17 +419,16 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(float* __restrict__ S, 
     // Look-ahead: while waves 1-3 apply the trailing update of block column J, wave 0 updates only the next
     // diagonal block and immediately factors/inverts it, so the serial 16x16 factorizations (the longest
     // single-wave stretch) hide behind the MFMA updates instead of adding to them.
-    if (w == 0) diag16_factor_invert(a, 0, dinv, info, (int)k0, lane);
+    if (w == 0) diag16_factor_invert(a, tdiag, 0, info, (int)k0, lane);
     __syncthreads();
     for (int J = 0; J < 8; ++J) {
         const int j0 = 16 * J;
-        const float* dJ = dinv + J * DINV_SZ;
         for (int I = J + 1 + w; I < 8; I += 4) {          // panel: P_I = A[I,J] * Dinv^T
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const float av = a[(16 * I + lr) * LDA + j0 + 4 * s + lg];
-                const float bv = dJ[lr * DINV_LD + 4 * s + lg];               // B[k][j] = Dinv[j][k]
+                const float bv = tri_t(a, tdiag, j0, lr, 4 * s + lg);          // B[k][j] = Dinv[j][k], j = lr, k = 4s+lg
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
             }
 #pragma unroll
@@ -436,21 +451,17 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(float* __restrict__ S, 
                 const float bv = a[(16 * K + lr) * LDA + j0 + 4 * s + lg];
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
             }
+            // a diagonal pair (I == K) also rewrites the upper half of its block: harmless, block K is not factored yet
 #pragma unroll
             for (int e = 0; e < 4; ++e) a[(16 * I + 4 * lg + e) * LDA + 16 * K + lr] = acc[e];
         }
-        if (w == 0) diag16_factor_invert(a, j0 + 16, dinv + (J + 1) * DINV_SZ, info, (int)(k0 + j0 + 16), lane);
+        if (w == 0) diag16_factor_invert(a, tdiag, j0 + 16, info, (int)(k0 + j0 + 16), lane);
         __syncthreads();
     }
-    // ---- T = L^-1 -----------------------------------------------------------------------------
-    for (int idx = tid; idx < 8 * 256; idx += 256) {       // diagonal 16-blocks of T
-        const int J = idx >> 8, rr = (idx >> 4) & 15, cc = idx & 15;
-        t[(16 * J + rr) * LDA + 16 * J + cc] = dinv[J * DINV_SZ + rr * DINV_LD + cc];
-    }
-    __syncthreads();
+    // ---- T = L^-1 by doubling; the diagonal 16-blocks of T are already in place ---------------------------------
     for (int hb = 1; hb <= 4; hb *= 2) {                   // half size in 16-blocks
-        const int h = 16 * hb, npairs = 8 / (2 * hb), nout = npairs * hb * hb;
-        // phase A: X = L21 * T11  -> upper mirror of a
+        const int h = 16 * hb, npairs = 8 / (2 * hb), nout = npairs * hb * hb;       // 4, 8, 16 output tiles
+        // phase A: X = L21 * T11 -> the upper block (rows c0.., columns c0+h..) that T21^T will occupy
         for (int o = w; o < nout; o += 4) {
             const int pr = o / (hb * hb), bi = (o / hb) % hb, bj = o % hb;
             const int c0 = pr * 2 * h;
@@ -459,7 +470,9 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(float* __restrict__ S, 
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const float av = a[(c0 + h + 16 * bi + lr) * LDA + c0 + 16 * kb + 4 * s + lg];
-                    const float bv = t[(c0 + 16 * kb + 4 * s + lg) * LDA + c0 + 16 * bj + lr];
+                    // B[k][j] = T11[k][j], k = 16kb+4s+lg >= j = 16bj+lr off the diagonal sub-block: stored at a[c0+j][c0+k]
+                    const float bv = (kb == bj) ? tri_t(a, tdiag, c0 + 16 * bj, 4 * s + lg, lr)
+                                                : a[(c0 + 16 * bj + lr) * LDA + c0 + 16 * kb + 4 * s + lg];
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
                 }
             }
@@ -467,35 +480,51 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(float* __restrict__ S, 
             for (int e = 0; e < 4; ++e) a[(c0 + 16 * bi + 4 * lg + e) * LDA + c0 + h + 16 * bj + lr] = acc[e];
         }
         __syncthreads();
-        // phase B: T21 = -T22 * X
-        for (int o = w; o < nout; o += 4) {
-            const int pr = o / (hb * hb), bi = (o / hb) % hb, bj = o % hb;
-            const int c0 = pr * 2 * h;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            for (int kb = 0; kb <= bi; ++kb) {
+        // phase B: T21 = -T22 * X, written TRANSPOSED over X's block: every tile is held in registers until all reads are done
+        f32x4 tb[4];
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const float av = -t[(c0 + h + 16 * bi + lr) * LDA + c0 + h + 16 * kb + 4 * s + lg];
-                    const float bv = a[(c0 + 16 * kb + 4 * s + lg) * LDA + c0 + h + 16 * bj + lr];
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+        for (int q = 0; q < 4; ++q) {
+            const int o = w + 4 * q;
+            tb[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (o < nout) {
+                const int pr = o / (hb * hb), bi = (o / hb) % hb, bj = o % hb;
+                const int c0 = pr * 2 * h;
+                for (int kb = 0; kb <= bi; ++kb) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        // A[i][k] = -T22[i][k], i = 16bi+lr, k = 16kb+4s+lg <= i: stored at a[c0+h+k][c0+h+i]
+                        const float tv = (kb == bi) ? tri_t(a, tdiag, c0 + h + 16 * bi, lr, 4 * s + lg)
+                                                    : a[(c0 + h + 16 * kb + 4 * s + lg) * LDA + c0 + h + 16 * bi + lr];
+                        const float bv = a[(c0 + 16 * kb + 4 * s + lg) * LDA + c0 + h + 16 * bj + lr];        // X[k][j]
+                        tb[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(-tv, bv, tb[q], 0, 0, 0);
+                    }
                 }
             }
+        }
+        __syncthreads();
 #pragma unroll
-            for (int e = 0; e < 4; ++e) t[(c0 + h + 16 * bi + 4 * lg + e) * LDA + c0 + 16 * bj + lr] = acc[e];
+        for (int q = 0; q < 4; ++q) {
+            const int o = w + 4 * q;
+            if (o < nout) {
+                const int pr = o / (hb * hb), bi = (o / hb) % hb, bj = o % hb;
+                const int c0 = pr * 2 * h;
+                // T21[i][j], i = 16bi+4lg+e, j = 16bj+lr  ->  a[c0+j][c0+h+i]: four consecutive floats per lane
+                float2* q2 = reinterpret_cast<float2*>(a + (c0 + 16 * bj + lr) * LDA + c0 + h + 16 * bi + 4 * lg);
+                q2[0] = make_float2(tb[q][0], tb[q][1]);
+                q2[1] = make_float2(tb[q][2], tb[q][3]);
+            }
         }
         __syncthreads();
     }
-    float* Tg = tinv + (int64_t)block_index * NB * NB;
+    // ---- store L (lower triangle of S) and T (row-major 128x128, zero above the diagonal) -----------------------
 #pragma unroll
     for (int hp = 0; hp < 2; ++hp) {       // LDS reads of 8 rows first (ds_read_b64), then their stores
-        float2 ql[8][2], zl[8][2];
+        float2 ql[8][2];
 #pragma unroll
         for (int pp = 0; pp < 8; ++pp) {
             const int r = (tid >> 5) + 8 * (hp * 8 + pp), c = (tid & 31) * 4;
             const float2* q = reinterpret_cast<const float2*>(a + r * LDA + c);
-            const float2* z = reinterpret_cast<const float2*>(t + r * LDA + c);
             ql[pp][0] = q[0]; ql[pp][1] = q[1];
-            zl[pp][0] = z[0]; zl[pp][1] = z[1];
         }
 #pragma unroll
         for (int pp = 0; pp < 8; ++pp) {
@@ -507,10 +536,23 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(float* __restrict__ S, 
                 if (c + 1 <= r) g[1] = ql[pp][0].y;
                 if (c + 2 <= r) g[2] = ql[pp][1].x;
             }
-            // T above the diagonal was never written in LDS: select, do not multiply
-            *reinterpret_cast<float4*>(Tg + r * NB + c) = make_float4(c + 0 <= r ? zl[pp][0].x : 0.f, c + 1 <= r ? zl[pp][0].y : 0.f,
-                                                                       c + 2 <= r ? zl[pp][1].x : 0.f, c + 3 <= r ? zl[pp][1].y : 0.f);
         }
+    }
+    // T[r][c] = a[c][r] (c < r): a transposed read.  Lane -> (row r = r0 + (lane & 15), quad of columns (lane >> 4)):
+    // the 64 reads of one instruction fall on 4 image rows x 16 consecutive words (2 lanes per bank), and the float4
+    // stores of a wave cover 16 rows x 64 contiguous bytes of the row-major T.
+    float* Tg = tinv + (int64_t)block_index * NB * NB;
+    for (int it = 0; it < 16; ++it) {
+        const int item = it * 4 + w;                       // 64 items: 8 row groups of 16 x 8 column groups of 16
+        const int r = 16 * (item >> 3) + lr, c = 16 * (item & 7) + 4 * lg;
+        float o4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int cc = c + q;
+            const float up = a[(cc < r ? cc : r) * LDA + (cc < r ? r : cc)];
+            o4[q] = cc < r ? up : (cc == r ? tdiag[r] : 0.f);
+        }
+        *reinterpret_cast<float4*>(Tg + r * NB + c) = make_float4(o4[0], o4[1], o4[2], o4[3]);
     }
 }
 
@@ -777,7 +819,7 @@ int launch_gemm(oisat_ctx* h, const char* name, float* C, int64_t ldc, const flo
 int potrf_rec(oisat_ctx* h, float* S, int64_t ld, int64_t mpb, int64_t b0, int64_t b1, float* tinv, int* info_dev) {
     if (b1 - b0 == 1) {
         const int64_t k0 = b0 * NB;
-        const size_t shm = sizeof(float) * (2 * NB * LDA + 8 * DINV_SZ);
+        const size_t shm = kDiagShm;
         OISAT_LAUNCH(h, "potrf_diag", potrf_diag_kernel, dim3(1), dim3(256), shm, S, ld, k0, tinv, info_dev, (int)b0);
         const int64_t rows = (mpb - b0 - 1) * NB;
         if (rows > 0) {
@@ -957,7 +999,7 @@ extern "C" int oisat_potrf(oisat_ctx* h, float* S, int64_t m, int64_t ld, int* i
     // per-function attributes, set once per process (handles may be driven from different host threads)
     static const hipError_t attr_rc = []() {
         hipError_t e = hipFuncSetAttribute((const void*)potrf_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)(sizeof(float) * (2 * NB * LDA + 8 * DINV_SZ)));
+                                           (int)kDiagShm);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)trsv_pipe_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)(sizeof(float) * NB * TLD));
@@ -1000,6 +1042,8 @@ extern "C" int oisat_potrf(oisat_ctx* h, float* S, int64_t m, int64_t ld, int* i
         HIP_TRY(hipStreamSynchronize(h->stream));
         *info_host = *pin;
         if (*pin != 0) {
+            // reported to the caller right here: do not report it a second time through oisat_solve_status
+            HIP_TRY(hipMemsetAsync(info_dev + 1, 0, 2 * sizeof(int), h->stream));
             oisat_set_error("potrf: matrix not positive definite at column %d", *pin);
             return OISAT_ENOTPD;
         }
@@ -1059,7 +1103,9 @@ extern "C" int oisat_gain_solve(oisat_ctx* h, const float* L, const double* oxyz
             HIP_TRY(hipMemcpyAsync(pe, h->ws[7], sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(hipStreamSynchronize(h->stream));
             if (*pe != 0) {
-                oisat_set_error("triangular solve: %u workgroup(s) gave up waiting for a predecessor (bounded spin)", *pe);
+                const unsigned gave_up = *pe;
+                HIP_TRY(hipMemsetAsync(h->ws[7], 0, 16, h->stream));      // reported here, not again by oisat_solve_status
+                oisat_set_error("triangular solve: %u workgroup(s) gave up waiting for a predecessor (bounded spin)", gave_up);
                 return OISAT_EHIP;
             }
         }

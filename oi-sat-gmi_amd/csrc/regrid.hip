@@ -206,12 +206,55 @@ __global__ __launch_bounds__(256) void nn_query_kernel(const double* __restrict_
 // (_find_simplex_directed): hop across the facet opposite the first barycentric coordinate below -eps,
 // leave the hull -> NaN; the walk starts at a simplex incident to the target's nearest swath pixel
 // (known from the neighbour search), so it takes a handful of hops.
+// scipy's _find_simplex_bruteforce (qhull.pyx), what _find_simplex_directed falls back to when the walk meets a
+// degenerate simplex (NaN transform / a coordinate above 1 + eps) or runs out of hops: bounding-box test, then every
+// simplex in index order -- a valid transform is tested with eps; a degenerate one (NaN transform) is replaced by its
+// valid neighbours, tested with the wider eps_broad = sqrt(DBL_EPSILON) on the side that faces the degenerate simplex.
+// Rare (regular swath grids can make qhull emit zero-area simplices), so a plain per-thread scan is fine.
+struct TriBounds { double xmin, xmax, ymin, ymax; };
+
+__device__ inline int32_t find_simplex_bruteforce(double x, double y, const int32_t* __restrict__ neighbors,
+                                                  const double* __restrict__ transform, int32_t ns, TriBounds bb, double eps,
+                                                  double& c0, double& c1, double& c2) {
+    const double eps_broad = 1.4901161193847656e-08;
+    if (x < bb.xmin - eps || x > bb.xmax + eps || y < bb.ymin - eps || y > bb.ymax + eps) return -1;
+    for (int32_t is = 0; is < ns; ++is) {
+        const double* tr = transform + (int64_t)is * 6;
+        if (tr[0] == tr[0]) {                                          // _barycentric_inside
+            const double dx = x - tr[4], dy = y - tr[5];
+            c0 = tr[0] * dx + tr[1] * dy;
+            if (!(-eps <= c0 && c0 <= 1.0 + eps)) continue;
+            c1 = tr[2] * dx + tr[3] * dy;
+            if (!(-eps <= c1 && c1 <= 1.0 + eps)) continue;
+            c2 = 1.0 - c0 - c1;
+            if (!(-eps <= c2 && c2 <= 1.0 + eps)) continue;
+            return is;
+        }
+        for (int k = 0; k < 3; ++k) {
+            const int32_t nb = neighbors[(int64_t)is * 3 + k];
+            if (nb == -1) continue;
+            const double* tn = transform + (int64_t)nb * 6;
+            if (tn[0] != tn[0]) continue;
+            const double dx = x - tn[4], dy = y - tn[5];
+            const double b0 = tn[0] * dx + tn[1] * dy, b1 = tn[2] * dx + tn[3] * dy;
+            const double b[3] = {b0, b1, 1.0 - b0 - b1};
+            bool inside = true;
+            for (int m = 0; m < 3; ++m) {
+                const double lo = (neighbors[(int64_t)nb * 3 + m] == is) ? -eps_broad : -eps;
+                if (!(lo <= b[m] && b[m] <= 1.0 + eps)) { inside = false; break; }
+            }
+            if (inside) { c0 = b[0]; c1 = b[1]; c2 = b[2]; return nb; }
+        }
+    }
+    return -1;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void linear_interp_kernel(const double* __restrict__ tx, const double* __restrict__ ty, int64_t Tn,
                                                              const int32_t* __restrict__ nn_idx, const int32_t* __restrict__ v2s,
                                                              const int32_t* __restrict__ simplices, const int32_t* __restrict__ neighbors,
                                                              const double* __restrict__ transform, int32_t ns, const T* __restrict__ values,
-                                                             int64_t P, int nfields, T* __restrict__ out) {
+                                                             int64_t P, int nfields, T* __restrict__ out, TriBounds bb) {
     const double eps = 100.0 * 2.220446049250313e-16;              // scipy: eps = 100 * DBL_EPSILON
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < Tn; t += stride) {
@@ -242,10 +285,14 @@ __global__ __launch_bounds__(256) void linear_interp_kernel(const double* __rest
                     }
                 }
                 if (go == -2) break;                                   // found
-                if (go < 0) { is = -1; break; }                        // left the hull (-1) or degenerate simplex (-3)
+                if (go == -1) { is = -1; break; }                      // left the hull: NaN, no second look (scipy: return -1)
+                if (go == -3) {                                        // degenerate simplex in the way: brute force
+                    is = find_simplex_bruteforce(x, y, neighbors, transform, ns, bb, eps, c0, c1, c2);
+                    break;
+                }
                 is = go;
             }
-            if (hop >= max_hops) is = -1;
+            if (hop >= max_hops) is = find_simplex_bruteforce(x, y, neighbors, transform, ns, bb, eps, c0, c1, c2);   // no convergence
         }
         if (is < 0) {
             for (int f = 0; f < nfields; ++f) out[(int64_t)f * Tn + t] = nan_of<T>();
@@ -680,18 +727,21 @@ extern "C" int oisat_rbf_interp(oisat_ctx* h, int dtype, const double* plon, con
 
 extern "C" int oisat_linear_interp(oisat_ctx* h, int dtype, const double* tlon, const double* tlat, int64_t Tn, const int32_t* nn_idx,
                                    const int32_t* vertex_to_simplex, const int32_t* simplices, const int32_t* neighbors,
-                                   const double* transform, int64_t nsimplex, const void* values, int64_t P, int nfields, void* out) {
+                                   const double* transform, int64_t nsimplex, const void* values, int64_t P, int nfields, void* out,
+                                   const double* bounds_host) {
     ARG_CHECK(h && tlon && tlat && nn_idx && vertex_to_simplex && simplices && neighbors && transform && values && out);
+    TriBounds bb = {-1e300, 1e300, -1e300, 1e300};                    // no bounds given: never "fully outside"
+    if (bounds_host) bb = TriBounds{bounds_host[0], bounds_host[1], bounds_host[2], bounds_host[3]};
     ARG_CHECK(Tn > 0 && nsimplex > 0 && nsimplex < (int64_t)INT32_MAX && P > 0 && nfields > 0);
     ARG_CHECK(dtype == OISAT_F32 || dtype == OISAT_F64);
     const int grid = stream_grid(Tn, 256);
     if (dtype == OISAT_F32) {
         OISAT_LAUNCH(h, "linear_interp", (linear_interp_kernel<float>), dim3(grid), dim3(256), 0, tlon, tlat, Tn, nn_idx,
-                     vertex_to_simplex, simplices, neighbors, transform, (int32_t)nsimplex, (const float*)values, P, nfields, (float*)out);
+                     vertex_to_simplex, simplices, neighbors, transform, (int32_t)nsimplex, (const float*)values, P, nfields, (float*)out, bb);
     } else {
         OISAT_LAUNCH(h, "linear_interp", (linear_interp_kernel<double>), dim3(grid), dim3(256), 0, tlon, tlat, Tn, nn_idx,
                      vertex_to_simplex, simplices, neighbors, transform, (int32_t)nsimplex, (const double*)values, P, nfields,
-                     (double*)out);
+                     (double*)out, bb);
     }
     return OISAT_OK;
 }

@@ -213,12 +213,15 @@ class DenseAnalysis:
         return m ** 3 / 3.0 + 2.0 * m ** 2
 
 
-def tile_partition(lat2, lon2, obs_lat, obs_lon, tile_deg=30.0, halo_km=900.0):
+def tile_partition(lat2, lon2, obs_lat, obs_lon, tile_deg=30.0, halo_km=900.0, merge_polar=True):
     """Localised block-B (BASELINE config 3): cut a regular lat/lon grid into tile_deg x tile_deg tiles;
     a tile is analysed with every observation inside the tile or within ``halo_km`` of it (3 L is the
     usual choice: exp(-9/2) = 1 % correlation left).  Returns a list of dicts with the tile's grid
     slices and the indices of its observations.  Longitude wraps; bands whose halo reaches a pole take
-    every longitude."""
+    every longitude -- all tiles of such a band then share ONE observation set, i.e. one and the same system
+    (H B H^T + R) z = d, so with ``merge_polar`` (default) the band is kept as a single polar-cap tile (all
+    longitudes) and that system is built, factored and solved once instead of once per 30 deg of longitude
+    (12 times at tile_deg = 30: 87 % of the factorization flops of a 720x1440 / 1e5-observation month)."""
     lat2 = np.asarray(lat2)
     lon2 = np.asarray(lon2)
     ny, nx = lat2.shape
@@ -233,7 +236,11 @@ def tile_partition(lat2, lon2, obs_lat, obs_lon, tile_deg=30.0, halo_km=900.0):
         la0, la1 = latc[y0] - dlat / 2, latc[y1 - 1] + dlat / 2
         in_lat = (olat >= la0 - h_lat) & (olat <= la1 + h_lat)
         worst = max(abs(la0 - h_lat), abs(la1 + h_lat))
-        h_lon = 360.0 if worst >= 89.0 else h_lat / np.cos(np.deg2rad(worst))
+        polar = worst >= 89.0
+        h_lon = 360.0 if polar else h_lat / np.cos(np.deg2rad(worst))
+        if polar and merge_polar:
+            tiles.append({"rows": (y0, y1), "cols": (0, nx), "obs": np.flatnonzero(in_lat)})
+            continue
         for x0 in range(0, nx, tx):
             x1 = min(x0 + tx, nx)
             lo0, lo1 = lonc[x0] - dlon / 2, lonc[x1 - 1] + dlon / 2
@@ -322,7 +329,9 @@ class TiledAnalysis:
     ``LanePool`` (heaviest first, each lane one stream with ONE shared factor workspace); across GPUs
     ``parallel.shard_units`` spreads (month x tile) units -- ``only`` restricts this object to the tiles a rank owns."""
 
-    def __init__(self, grid_lat, grid_lon, tile_deg=30.0, halo_km=900.0, dtype=np.float32, ctx=None, streams=12, pool=None):
+    def __init__(self, grid_lat, grid_lon, tile_deg=30.0, halo_km=900.0, dtype=np.float32, ctx=None, streams=12, pool=None,
+                 merge_polar=True):
+        self.merge_polar = bool(merge_polar)
         self.pool = pool or LanePool(ctx, streams)
         self.ctx = self.pool.ctx
         self.lanes = self.pool.lanes
@@ -341,7 +350,7 @@ class TiledAnalysis:
         y = np.where(np.ravel(obs_y) < 0, 0.0, np.ravel(obs_y))
         self._host = dict(Xa=Xa, Sa=np.asarray(Sa), scale=float(scale), olat=olat, olon=olon, ovar=np.ravel(obs_var),
                           d=y - Xa.ravel()[cell], s=sig.ravel()[cell])
-        self.tiles = tile_partition(self.lat2, self.lon2, olat, olon, self.tile_deg, self.halo_km)
+        self.tiles = tile_partition(self.lat2, self.lon2, olat, olon, self.tile_deg, self.halo_km, self.merge_polar)
         nx = self.lat2.shape[1]
         self._cell, self._Sa, self._scale = cell, np.asarray(Sa), float(scale)
         self._inside = [None] * len(self.tiles)

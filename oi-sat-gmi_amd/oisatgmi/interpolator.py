@@ -117,6 +117,8 @@ class TriIndex:
         self.transform = ctx.upload(tri.transform, dtype=np.float64)
         self.v2s = ctx.upload(tri.vertex_to_simplex, dtype=np.int32)
         self.P = int(tri.points.shape[0])
+        self.bounds = (_hip.C.c_double * 4)(float(tri.min_bound[0]), float(tri.max_bound[0]), float(tri.min_bound[1]),
+                                             float(tri.max_bound[1]))
 
     @classmethod
     def from_points(cls, lon, lat):
@@ -133,7 +135,7 @@ class TriIndex:
         out = ctx.alloc(nfields * T * dt.itemsize)
         ctx.check(ctx.lib.oisat_linear_interp(ctx.h, _hip.dtype_code(dt), tgt_buf.at(0), tgt_buf.at(T * 8), T, nn_idx_buf.ptr,
                                               self.v2s.ptr, self.simplices.ptr, self.neighbors.ptr, self.transform.ptr, self.ns,
-                                              values_buf.ptr, self.P, nfields, out.ptr))
+                                              values_buf.ptr, self.P, nfields, out.ptr, self.bounds))
         return out
 
 

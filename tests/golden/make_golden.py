@@ -275,6 +275,30 @@ def gen_interpolator_levels():
     save("interpolator_levels.npz", **out)
 
 
+def gen_linear_degenerate():
+    """_interpolosis type 1 on a triangulation that holds DEGENERATE simplices (NaN barycentric transforms): an exactly
+    regular pixel lattice whose latitudes carry 1e-13 deg of noise, so qhull closes the hull with zero-area slivers.
+    scipy's point location then leaves its directed walk for the brute-force scan; targets sit on and around the hull."""
+    from scipy.spatial import Delaunay, cKDTree
+    rng = np.random.default_rng(777)
+    lon1, lat1 = np.arange(0.0, 6.0, 0.25), np.arange(10.0, 14.0, 0.25)
+    LON, LAT = np.meshgrid(lon1, lat1)
+    pts = np.column_stack((LON.ravel(), LAT.ravel() + 1e-13 * rng.normal(size=LON.size)))
+    tri = Delaunay(pts)
+    nbad = int(np.isnan(tri.transform[:, 0, 0]).sum())
+    assert nbad > 0
+    Z = (1.0 + np.sin(pts[:, 0]) * np.cos(pts[:, 1] / 3.0)).reshape(LON.shape)
+    gx, gy = np.meshgrid(np.arange(-0.25, 6.01, 0.0625), np.arange(9.75, 14.01, 0.0625))
+    # plus targets exactly on pixel rows / hull edges
+    X = np.concatenate([gx.ravel(), lon1, lon1 + 0.125, np.full(lat1.size, 0.0), np.full(lat1.size, 5.75)])
+    Y = np.concatenate([gy.ravel(), np.full(lon1.size, 10.0), np.full(lon1.size, 13.75), lat1 + 0.1, lat1 + 0.1])
+    X, Y = X.reshape(1, -1), Y.reshape(1, -1)
+    dists, _ = cKDTree(pts).query(np.column_stack((X.ravel(), Y.ravel())))
+    dists = dists.reshape(X.shape)
+    out = REF_interp._interpolosis(tri, Z, X, Y, 1, dists, 0.25)
+    save("interpolator_degenerate.npz", pts=pts, Z=Z, X=X, Y=Y, dists=dists, out=out, n_degenerate=nbad)
+
+
 def amf_cases():
     """name -> (ctm_data, sat_data) builders shared with the tests (seeded)"""
     def case_a():
@@ -384,6 +408,9 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["akconv"]:
         gen_ak_conv()
         raise SystemExit(0)
+    if sys.argv[1:] == ["degenerate"]:
+        gen_linear_degenerate()
+        raise SystemExit(0)
     if sys.argv[1:] == ["levels"]:
         gen_interpolator_levels()
         raise SystemExit(0)
@@ -401,6 +428,7 @@ if __name__ == "__main__":
     gen_interpolator()
     gen_interpolator_rbf()
     gen_interpolator_levels()
+    gen_linear_degenerate()
     gen_amf_recal()
     gen_ak_conv()
     gen_pwv()

@@ -967,10 +967,19 @@ def test_tiled_block_b_analysis(ctx):
     covered = np.zeros((ny, nx), dtype=int)
     for t in ta.tiles:
         covered[t["rows"][0]:t["rows"][1], t["cols"][0]:t["cols"][1]] += 1
-    assert (covered == 1).all() and len(ta.tiles) == 3 * 6
+    # two polar bands (their halo reaches the pole: one cap tile each, all longitudes) + 6 tiles in the middle band
+    assert (covered == 1).all() and len(ta.tiles) == 1 + 6 + 1
+    tu = dense.TiledAnalysis(p.lat, p.lon, tile_deg=60.0, halo_km=3 * L, dtype=np.float32, pool=ta.pool, merge_polar=False)
+    tu.load(p.Xa, p.Sa, p.obs_lat, p.obs_lon, p.obs_y, p.obs_var)
+    assert len(tu.tiles) == 3 * 6
     ta.run(L, refine=2, check_pd=True)
     xa, inc = ta.download()
+    # merging a polar band into one cap tile changes nothing but the number of factorizations: same observation set,
+    # same system, same increments as the band cut every 60 deg of longitude
+    tu.run(L, refine=2, check_pd=True)
+    xu, incu = tu.download()
     scale = np.abs(p.Xa).max()
+    assert np.abs(inc - incu).max() <= 2e-6 * scale
     for t in ta.tiles:
         (y0, y1), (x0, x1) = t["rows"], t["cols"]
         o = t["obs"]

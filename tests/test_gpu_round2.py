@@ -188,8 +188,8 @@ def test_oi_dense_mode_spreads_increments(ctx):
 # full-size checks (BASELINE configs[2] as worded, configs[4])
 # ------------------------------------------------------------------------------------------------
 def test_tiled_config3_full_size_properties(ctx):
-    """Localised block-B at FULL size: 720x1440 grid, ~1e5 swath observations, 72 tiles of 30 deg with a 3 L halo, twelve
-    lanes.  Per tile (every tile): float64 residual of (H B H^T + R) z = d on random rows and the increment B H^T z on
+    """Localised block-B at FULL size: 720x1440 grid, ~1e5 swath observations, 30 deg tiles with a 3 L halo, twelve
+    lanes (the two polar bands are single cap tiles: dense.tile_partition).  Per tile (every tile): float64 residual of (H B H^T + R) z = d on random rows and the increment B H^T z on
     random cells, both re-derived on the host from the oracle's covariance formula with the tile's own observation set."""
     L = 300.0
     p = syn.point_obs_case(720, 1440, 100000, 4000, swaths=True)
@@ -197,7 +197,7 @@ def test_tiled_config3_full_size_properties(ctx):
     y = np.where(p.obs_y < 0, 0, p.obs_y)
     ta = dense.TiledAnalysis(p.lat, p.lon, tile_deg=30.0, halo_km=3.0 * L, dtype=np.float32)
     ta.load(p.Xa, p.Sa, p.obs_lat, p.obs_lon, p.obs_y, p.obs_var)
-    assert len(ta.tiles) == 72 and all(t["obs"].size > 1000 for t in ta.tiles)
+    assert len(ta.tiles) == 1 + 4 * 12 + 1 and all(t["obs"].size > 1000 for t in ta.tiles)     # two polar caps + 48 tiles
     ta.run(L, refine=2, check_pd=True)
     xa, inc = ta.download()
     assert np.isfinite(xa).all() and np.isfinite(inc).all()
@@ -272,7 +272,7 @@ def test_month_tile_batch_equals_per_month_tiled_analysis(ctx):
     ny, nx, L = 36, 72, 400.0
     lat, lon = syn.global_grid(ny, nx)
     months = {k: syn.point_obs_case(ny, nx, 700 + 100 * k, 8100 + k) for k in range(3)}
-    owned = {0: [0, 3, 4, 17], 1: [5], 2: [1, 2, 9, 10, 11]}
+    owned = {0: [0, 3, 4, 7], 1: [5], 2: [1, 2, 6]}            # tiles: 0 = south cap, 1..6 = middle band, 7 = north cap
     batch = dense.MonthTileBatch(lat, lon, tile_deg=60.0, halo_km=3 * L, dtype=np.float32, streams=4)
     for k, p in months.items():
         batch.add_month(k, p.Xa, p.Sa, p.obs_lat, p.obs_lon, p.obs_y, p.obs_var, only=owned[k])
@@ -362,3 +362,17 @@ def test_averaging_promotes_mixed_dtype_stacks_like_numpy(ctx):
     ref = orc.averaging("2019-06-01", "2019-07-01", r, amf_type=cfg.satellite_amf, opt_type=cfg.satellite_opt)
     for a, b in zip(res[:5], ref[:5]):
         np.testing.assert_allclose(a, b, rtol=RT64, equal_nan=True)
+
+
+def test_linear_interpolation_survives_degenerate_simplices(ctx, golden):
+    """qhull can close the hull of a (nearly) regular pixel lattice with zero-area simplices whose barycentric
+    transform is NaN; scipy's directed walk then falls back to its brute-force scan and still returns values.  Golden:
+    the reference's _interpolosis(type 1) on such a triangulation (tests/golden/make_golden.py gen_linear_degenerate)."""
+    from scipy.spatial import Delaunay
+    from oisatgmi.interpolator import _interpolosis
+    g = golden("interpolator_degenerate.npz")
+    tri = Delaunay(g["pts"])
+    assert int(np.isnan(tri.transform[:, 0, 0]).sum()) == int(g["n_degenerate"]) > 0
+    got = _interpolosis(tri, g["Z"], g["X"], g["Y"], 1, g["dists"], 0.25)
+    assert np.array_equal(np.isnan(got), np.isnan(g["out"]))
+    np.testing.assert_allclose(got, g["out"], rtol=RT64, equal_nan=True)
