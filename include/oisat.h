@@ -56,6 +56,10 @@ int oisat_device_info(oisat_ctx* h, char* name_out, int name_cap, int* cu_count,
 int oisat_set_stream(oisat_ctx* h, void* hip_stream);       /* NULL = the default stream */
 int oisat_stream_create(oisat_ctx* h);                      /* give this handle its own non-blocking stream: several
                                                                handles on one device then run concurrently (tiles) */
+int oisat_bind_thread(oisat_ctx* h);                        /* hipSetDevice(handle's device) for the CALLING host thread:
+                                                               HIP's current device is per thread, so a worker thread that
+                                                               drives a handle calls this once before anything else.  One
+                                                               handle is driven by one host thread at a time. */
 int oisat_sync(oisat_ctx* h);                               /* hipStreamSynchronize(stream) */
 int oisat_dmalloc(oisat_ctx* h, size_t bytes, void** dev_out);
 int oisat_dfree(oisat_ctx* h, void* dev);

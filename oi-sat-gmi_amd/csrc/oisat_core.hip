@@ -78,6 +78,12 @@ extern "C" int oisat_stream_create(oisat_ctx* h) {
     return OISAT_OK;
 }
 
+extern "C" int oisat_bind_thread(oisat_ctx* h) {
+    ARG_CHECK(h != nullptr);
+    HIP_TRY(hipSetDevice(h->device));       // the current device is per host thread in HIP
+    return OISAT_OK;
+}
+
 extern "C" int oisat_sync(oisat_ctx* h) {
     ARG_CHECK(h != nullptr);
     HIP_TRY(hipStreamSynchronize(h->stream));

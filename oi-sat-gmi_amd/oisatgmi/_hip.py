@@ -30,6 +30,7 @@ SIGNATURES = {
     "oisat_device_info": (C.c_int, [_c_ctx, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(_i64)]),
     "oisat_set_stream": (C.c_int, [_c_ctx, _ptr]),
     "oisat_stream_create": (C.c_int, [_c_ctx]),
+    "oisat_bind_thread": (C.c_int, [_c_ctx]),
     "oisat_sync": (C.c_int, [_c_ctx]),
     "oisat_dmalloc": (C.c_int, [_c_ctx, C.c_size_t, C.POINTER(_ptr)]),
     "oisat_dfree": (C.c_int, [_c_ctx, _ptr]),
@@ -223,6 +224,10 @@ class Context:
         """Give this handle a stream of its own (used for concurrent tiles)."""
         self.check(self.lib.oisat_stream_create(self.h))
         return self
+
+    def bind_thread(self):
+        """Make this handle's device the calling thread's current HIP device (per-thread state in HIP)."""
+        self.check(self.lib.oisat_bind_thread(self.h))
 
     def sync(self):
         self.check(self.lib.oisat_sync(self.h))

@@ -17,6 +17,7 @@ Pipeline (all in HBM, csrc/dense_cov.hip + csrc/dense_chol.hip):
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -284,6 +285,7 @@ class LanePool:
         self.ctx = ctx or _hip.context()
         self.lanes = [self.ctx] + [_hip.Context(self.ctx.device).own_stream() for _ in range(max(0, int(streams) - 1))]
         self.factors = [SharedFactor(lane) for lane in self.lanes]
+        self._threads = None
 
     def __len__(self):
         return len(self.lanes)
@@ -303,6 +305,29 @@ class LanePool:
         for lane in self.lanes:
             lane.sync()
 
+    def enqueue(self, per_lane):
+        """``per_lane[li]``: the callables (each enqueues one unit's kernels) of lane li, in run order.  One host thread
+        per lane: a 6,000-observation tile is ~150 kernel launches and a month ~8,000, so a single enqueueing thread --
+        ~10 us per launch -- is slower than the GPU (91 ms of launching for 30 ms of work at 720x1440 / 1e5 obs);
+        ctypes releases the GIL inside the library calls, and each handle is driven by exactly one thread."""
+        work = [(li, fns) for li, fns in enumerate(per_lane) if fns]
+        if len(work) <= 1 or os.environ.get("OISAT_ENQUEUE_THREADS", "1") == "0":
+            for _, fns in work:
+                for fn in fns:
+                    fn()
+            return
+        if self._threads is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._threads = ThreadPoolExecutor(max_workers=len(self.lanes), thread_name_prefix="oisat-lane")
+
+        def drive(li, fns):
+            self.lanes[li].bind_thread()
+            for fn in fns:
+                fn()
+        futures = [self._threads.submit(drive, li, fns) for li, fns in work]
+        for f in futures:
+            f.result()                                   # re-raises a worker's exception
+
     def check(self, what="tiled analysis"):
         """Wait for every lane and read (and clear) every lane's solve status before raising, so that one failed unit
         is reported once and does not poison the next run."""
@@ -316,6 +341,9 @@ class LanePool:
             raise _hip.OisatError("; ".join(errors))
 
     def close(self):
+        if self._threads is not None:
+            self._threads.shutdown(wait=True)
+            self._threads = None
         for f in self.factors:
             if f.buf is not None:
                 f.buf.free()
@@ -387,6 +415,7 @@ class TiledAnalysis:
             p.load_obs_direct(h["olat"][o], h["olon"][o], h["s"][o], h["ovar"][o], h["d"][o])
             self.plans[ti] = p
         self._order = [self.live[k] for k in (order if order is not None else range(len(self.live)))]
+        self._lane_of = {ti: lane_of[k] for k, ti in enumerate(self.live)}
         self._host = None
 
     def load(self, Xa, Sa, obs_lat, obs_lon, obs_y, obs_var, scale=1.0, only=None):
@@ -394,8 +423,10 @@ class TiledAnalysis:
         self.build()
 
     def enqueue(self, L_km, refine=1, check_pd=False):
-        for ti in self._order:
-            self.plans[ti].run(L_km, refine=refine, check_pd=check_pd)
+        per_lane = [[] for _ in self.lanes]
+        for ti in self._order:                           # run order (heaviest first) is kept inside every lane
+            per_lane[self._lane_of[ti]].append(lambda p=self.plans[ti]: p.run(L_km, refine=refine, check_pd=check_pd))
+        self.pool.enqueue(per_lane)
 
     def run(self, L_km, refine=1, check_pd=False):
         """Enqueue every tile on its lane's stream (largest first), wait for all lanes and check their solve status:
@@ -480,8 +511,11 @@ class MonthTileBatch:
 
     def run(self, L_km, refine=1, check_pd=False, wait=True):
         self.ctx.sync()
+        per_lane = [[] for _ in self.pool.lanes]
         for key, ti in self._run_order:                  # heaviest unit first, across months
-            self.months[key].plans[ti].run(L_km, refine=refine, check_pd=check_pd)
+            ta = self.months[key]
+            per_lane[ta._lane_of[ti]].append(lambda p=ta.plans[ti]: p.run(L_km, refine=refine, check_pd=check_pd))
+        self.pool.enqueue(per_lane)
         if wait:
             self.pool.check("month x tile batch")
 
