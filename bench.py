@@ -63,6 +63,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--tier-a-only", action="store_true", help="run only the reference-parity (Tier-A) kernel legs (profiling aid)")
     ap.add_argument("--no-config4", action="store_true", help="skip the fixed-workload strong-scaling leg (12 months x tiles)")
     ap.add_argument("--c4-months", type=int, default=12)
     ap.add_argument("--c4-passes", type=int, default=2)
@@ -461,7 +462,7 @@ def config4_leg(ctx, args, world, rank, local, lat2, lon2, sync, barrier):
 
     def one_pass():
         batch.run(L, refine=refine, wait=False)           # enqueue the whole shard, heaviest unit first
-        batch.pool.check("config 4 shard")                # wait for the lanes; any failed solve raises
+        batch.check()                                     # wait for the lanes; any failed solve raises
         if world > 1:
             return parallel.gather_to_root(send)           # the one collective of the data path
         return [send]
@@ -545,6 +546,9 @@ def main():
     if args.refine is not None:
         refine = args.refine
     n = ny * nx
+    if args.tier_a_only:
+        print(json.dumps({"tier_a": tier_a_leg(ctx, ny, nx, nobs, sync), "tier_a_kernels": tier_a_kernels_leg(ctx, sync)}))
+        return
     # ---- shared grid: built on rank 0, broadcast once (RCCL) -------------------------------------
     lat2, lon2 = syn.global_grid(ny, nx)
     if world > 1:
@@ -613,6 +617,35 @@ def main():
             conc = {"months_in_flight": len(plans), "value": len(plans) * ny2 * nx2 * 10 / el4, "unit": "grid-cells/s",
                     "ms_per_month": 1e3 * el4 / (10 * len(plans))}
             del plans
+            # the same eight months with their factorizations advanced in LOCK-STEP (oisat_batch_potrf: one launch per
+            # recursion node for all eight) between a per-lane build phase and a per-lane solve phase
+            blanes = [ctx] + lanes
+            bplans = []
+            for i, l in enumerate(blanes):
+                pb, cellb, _, _ = build_case(SECONDARY, 4000 + i)
+                q = dense.DenseAnalysis(pb.lat, pb.lon, max_obs=int(pb.obs_y.size), dtype=np.float32, ctx=l, batched=True)
+                q.load_background(pb.Xa, pb.Sa)
+                q.load_obs(pb.obs_lat, pb.obs_lon, cellb, np.where(pb.obs_y < 0, 0, pb.obs_y), pb.obs_var)
+                bplans.append(q)
+            bf = dense.BatchedFactor(ctx.device, bplans)
+
+            def months_batched():
+                for q in bplans:
+                    q.run_build(L2)
+                bf.factor()
+                for q in bplans:
+                    q.run_solve(r2)
+                for l in blanes:
+                    l.sync()
+            months_batched()
+            for q in bplans:
+                q.check()
+            bf.check()
+            el5 = time_steps(months_batched, 10, 2, sync)
+            conc["batched"] = {"months": len(bplans), "value": len(bplans) * ny2 * nx2 * 10 / el5, "unit": "grid-cells/s",
+                               "ms_per_month": 1e3 * el5 / (10 * len(bplans))}
+            bf.close()
+            del bplans
             for l in lanes:
                 l.close()
             out["secondary"] = {"workload": SECONDARY, "value": ny2 * nx2 * 20 / el2, "unit": "grid-cells/s",

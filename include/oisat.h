@@ -60,6 +60,9 @@ int oisat_bind_thread(oisat_ctx* h);                        /* hipSetDevice(hand
                                                                HIP's current device is per thread, so a worker thread that
                                                                drives a handle calls this once before anything else.  One
                                                                handle is driven by one host thread at a time. */
+int oisat_wait_for(oisat_ctx* waiter, oisat_ctx* signaler); /* work enqueued on waiter's stream after this call starts only
+                                                               when everything enqueued on signaler's stream so far is
+                                                               done (event record + stream wait; nothing blocks the host) */
 int oisat_sync(oisat_ctx* h);                               /* hipStreamSynchronize(stream) */
 int oisat_dmalloc(oisat_ctx* h, size_t bytes, void** dev_out);
 int oisat_dfree(oisat_ctx* h, void* dev);
@@ -295,6 +298,28 @@ int oisat_posterior_error(oisat_ctx* h, const float* L, int64_t m, int64_t ld, c
  * (the dense counterpart of AK = 1 - Sb/(Sa*reg), optimal_interpolation.py:31).  ak_out: dev double[m]. */
 int oisat_gain_diag(oisat_ctx* h, const float* L, int64_t m, int64_t ld, const double* ovar, int64_t chunk_rows,
                     double* ak_out);
+
+/* ---- batched factorization: many independent systems in lock-step ---------------------------------------------------
+ * The tiles of a localised analysis (and the months of a batch) are small systems -- 4,000-18,000 observations -- whose
+ * factorization is a chain of ~3 dependent launches per 128 columns, most of them far too small to fill 256 CUs.
+ * oisat_batch_potrf advances all matrices of a batch through the SAME recursion at once: every launch covers every
+ * matrix the step applies to (blockIdx.y = matrix), so the chain is paid once per batch and the launches are large.
+ * The recursion tree is that of the LARGEST matrix of the batch: its factor is bit-identical to oisat_potrf's, the
+ * smaller ones see their trailing updates associated differently and agree with oisat_potrf to fp32 rounding.
+ *
+ * oisat_batch_create: S[i] (dev, m[i] rows padded to roundup(m[i],128), leading dimension ld[i]) and tinv[i] (dev,
+ *   roundup(m[i],128)*128 floats: receives the inverted diagonal blocks) for nmat matrices; HOST arrays of device pointers
+ *   / sizes, copied.  The batch belongs to handle h and is factored on h's stream.
+ * oisat_batch_potrf: pad + factor every matrix in place.  info_host (may be NULL; then failures are left to
+ *   oisat_solve_status): int[2] = {first non-positive pivot column (1-based, 0 = none), index of that matrix}; synchronises.
+ * oisat_factor_adopt: tell handle h that L (as factored by a batch, or by oisat_potrf on another handle) with inverted
+ *   diagonal blocks tinv is "its" factor, so that oisat_gain_solve / oisat_potrs / oisat_trsm_rows / oisat_posterior_error
+ *   on h accept it.  The caller orders the streams (oisat_wait_for). */
+int oisat_batch_create(oisat_ctx* h, int nmat, float* const* S, const int64_t* m, const int64_t* ld, float* const* tinv,
+                       int* batch_id_out);
+int oisat_batch_potrf(oisat_ctx* h, int batch_id, int* info_host);
+int oisat_batch_destroy(oisat_ctx* h, int batch_id);
+int oisat_factor_adopt(oisat_ctx* h, const float* L, int64_t m, int64_t ld, float* tinv);
 
 /* Status of the dense solves enqueued on this handle since the last call with clear != 0 (synchronises the stream; one
  * 20-byte read-back).  oisat_potrf / oisat_gain_solve only report failures when given info_host / resid_host; an

@@ -29,6 +29,8 @@
 // runs on MFMA.  The inverses are kept: the triangular solves reuse them.
 #include "oisat_common.h"
 
+#include <algorithm>
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -37,18 +39,76 @@ constexpr int NB = 128;          // diagonal block / tile edge
 constexpr int BK = 32;           // K step
 constexpr int LDSW = 36;         // padded LDS row stride in floats (144 B, 16-B aligned)
 
+// ---- batched launches -------------------------------------------------------------------------
+// Many independent factorizations (the tiles of a localised analysis, the months of a batch) advance in LOCK-STEP:
+// one launch applies the same node of the recursion to every matrix -- blockIdx.y picks the matrix from a device
+// table, blockIdx.x its tile -- so that a step which is a 1-workgroup kernel or a 40-tile GEMM for one 6,000-
+// observation tile becomes one launch that fills the chip, and the chain of dependent launches is paid once per batch
+// instead of once per tile.  The table is sorted by block count (largest first): the matrices a node applies to are a
+// prefix of it.  Operands are derived in the kernel from (table entry, node), so nothing is uploaded per launch.
+struct BatchArgs {
+    const BatchMat* mats;        // nullptr: not a batched launch
+    int kind;                    // 0: trailing update of node (b0, mid, b1);  1: TRSM of the panel below diagonal block b0
+    int b0, mid, b1;
+};
+
+// operands of matrix `which` for this node, in units of `unit` rows/columns (128 or 64); false: the node does not apply
+__device__ __forceinline__ bool batch_operands(const BatchArgs& ba, int which, int unit, float*& C, int64_t& ldc, const float*& A,
+                                               int64_t& lda, const float*& B, int64_t& ldb, int& ntm, int& ntn) {
+    const BatchMat m = ba.mats[which];
+    const int per = NB / unit;
+    if (ba.kind == 0) {                                     // S[mid:, mid:b1] -= L[mid:, b0:mid] * L[mid:b1, b0:mid]^T
+        const int rows = m.mpb - ba.mid, cols = (ba.b1 < m.mpb ? ba.b1 : m.mpb) - ba.mid;
+        if (rows <= 0 || cols <= 0) return false;
+        ntm = rows * per;
+        ntn = cols * per;
+        C = m.S + (int64_t)ba.mid * NB * m.ld + (int64_t)ba.mid * NB;
+        A = m.S + (int64_t)ba.mid * NB * m.ld + (int64_t)ba.b0 * NB;
+        B = A;
+        ldc = lda = ldb = m.ld;
+    } else {                                                // P <- P * T_b0^T, P = S[(b0+1)*128:, b0*128 : (b0+1)*128], in place
+        const int rows = m.mpb - ba.b0 - 1;
+        if (rows <= 0) return false;
+        ntm = rows * per;
+        ntn = per;
+        float* P = m.S + (int64_t)(ba.b0 + 1) * NB * m.ld + (int64_t)ba.b0 * NB;
+        C = P;
+        A = P;
+        ldc = lda = m.ld;
+        B = m.tinv + (int64_t)ba.b0 * NB * NB;
+        ldb = NB;
+    }
+    return true;
+}
+
 // ---- gemm_nt ---------------------------------------------------------------------------------
 // mode 0: C -= A*B^T      mode 1: C = A*B^T (C may alias A when N == K == 128: TRSM-as-GEMM)
 // lower != 0: the C region is anchored on the diagonal; tiles strictly above it are skipped.
+template <bool BATCH>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(float* C, int64_t ldc, const float* A,
                                                           int64_t lda, const float* __restrict__ B, int64_t ldb, int ntm,
-                                                          int ntn, int K, int mode, int lower, int ntiles_total) {
+                                                          int ntn, int K, int mode, int lower, int ntiles_total, BatchArgs ba) {
     __shared__ __attribute__((aligned(16))) float lds[2][2][NB * BK];        // [buf][A|B][row*32 + 4*(chunk ^ (row&7))] = 65,536 B
-    // XCD-aware, bijective remap: blocks b, b+8, b+16.. share an XCD -> give each XCD a contiguous strip
-    const int nwg = gridDim.x;
-    const int orig = blockIdx.x;
-    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    int wg;
+    if (BATCH) {
+        const float* Bb = nullptr;
+        // Workgroups go to the 8 XCDs round-robin in dispatch order (x fastest, then y).  Same bijective remap as below
+        // over the whole 2-D grid: each XCD gets a contiguous run of (matrix, tile) pairs, i.e. neighbouring tiles of
+        // the same matrix share its L2.
+        const int64_t total = (int64_t)gridDim.x * gridDim.y, orig = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+        const int64_t xcd = orig & 7, q = total >> 3, r = total & 7;
+        const int64_t lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+        const int which = (int)(lin / gridDim.x);
+        if (!batch_operands(ba, which, NB, C, ldc, A, lda, Bb, ldb, ntm, ntn)) return;
+        B = Bb;
+        wg = (int)(lin - (int64_t)which * gridDim.x);
+    } else {
+        // XCD-aware, bijective remap: blocks b, b+8, b+16.. share an XCD -> give each XCD a contiguous strip
+        const int nwg = gridDim.x;
+        const int orig = blockIdx.x;
+        const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
     // wg -> tile in ROW-BAND order: bands of 8 tile rows, inside a band column by column.  64 consecutive
     // workgroups (what one XCD runs at once: 32 CUs x 2) are then an 8x8 patch of tiles: per K-step they
     // pull 8 A + 8 B tiles through the XCD's L2 instead of 64 + 1 for a column strip.  In `lower` mode only
@@ -57,6 +117,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(float* C, int64_t ldc, 
     int ti = 0, tj = 0;
     {
         int rem = wg;
+        bool found = false;
         for (int R0 = 0; R0 < ntm; R0 += 8) {
             const int R1 = (R0 + 7 < ntm ? R0 + 7 : ntm - 1), nr = R1 - R0 + 1;
             const int cmax = lower ? (R1 < ntn - 1 ? R1 : ntn - 1) : ntn - 1;       // last column of this band
@@ -74,10 +135,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(float* C, int64_t ldc, 
                     tj = c;
                     ti = c + rem;
                 }
+                found = true;
                 break;
             }
             rem -= count;
         }
+        if (BATCH && !found) return;                        // this matrix has fewer tiles than the largest of the batch
     }
     (void)ntiles_total;
     const int t = threadIdx.x;
@@ -169,18 +232,28 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(float* C, int64_t ldc, 
 // 4 waves as 2x2, one 32x32 MFMA tile per wave, BK = 32, same LDS image rows (36-float stride), same k permutation
 // and per-element accumulation order as gemm_nt_kernel (bit-identical results).
 constexpr int SB = 64;
+template <bool BATCH>
 __global__ __launch_bounds__(256) void gemm_nt_small_kernel(float* C, int64_t ldc, const float* A, int64_t lda,
                                                              const float* __restrict__ B, int64_t ldb, int ntm, int ntn, int K,
-                                                             int mode, int lower) {
+                                                             int mode, int lower, BatchArgs ba) {
     __shared__ __attribute__((aligned(16))) float lds[2][2][SB * LDSW];       // 36,864 B
+    if (BATCH) {
+        const float* Bb = nullptr;
+        if (!batch_operands(ba, blockIdx.y, SB, C, ldc, A, lda, Bb, ldb, ntm, ntn)) return;
+        B = Bb;
+    }
     // tile decode: column-major; in `lower` mode column c holds rows c .. ntm-1 (units of 64)
     int ti, tj;
     {
         int rem = blockIdx.x;
-        if (!lower) { tj = rem / ntm; ti = rem - tj * ntm; }
-        else {
+        if (!lower) {
+            tj = rem / ntm;
+            ti = rem - tj * ntm;
+            if (BATCH && tj >= ntn) return;
+        } else {
             int c = 0;
-            while (rem >= ntm - c) { rem -= ntm - c; ++c; }
+            while (c < ntn && rem >= ntm - c) { rem -= ntm - c; ++c; }
+            if (BATCH && c >= ntn) return;
             tj = c;
             ti = c + rem;
         }
@@ -247,10 +320,17 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(float* C, int64_t ld
 // The in-place TRSM-as-GEMM (C aliases A, N == K == 128) cannot use 64-wide tiles: a tile would overwrite panel columns
 // its row neighbour still reads.  64 rows x all 128 columns per workgroup instead (each wave 32 x 64 = two MFMA tiles):
 // a workgroup owns whole rows and has read every K-tile of them before its epilogue writes.
+template <bool BATCH>
 __global__ __launch_bounds__(256) void gemm_nt_rows64_kernel(float* C, int64_t ldc, const float* A, int64_t lda,
-                                                              const float* __restrict__ B, int64_t ldb, int K, int mode) {
+                                                              const float* __restrict__ B, int64_t ldb, int K, int mode, BatchArgs ba) {
     __shared__ __attribute__((aligned(16))) float ldsA[2][SB * LDSW];        // 18,432 B
     __shared__ __attribute__((aligned(16))) float ldsB[2][NB * LDSW];        // 36,864 B
+    if (BATCH) {
+        int ntm, ntn;
+        const float* Bb = nullptr;
+        if (!batch_operands(ba, blockIdx.y, SB, C, ldc, A, lda, Bb, ldb, ntm, ntn) || (int)blockIdx.x >= ntm) return;
+        B = Bb;
+    }
     const int ti = blockIdx.x;
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
     const int wr = wid >> 1, wc = wid & 1;
@@ -381,6 +461,7 @@ __device__ __forceinline__ void diag16_factor_invert(float* a, float* tdiag, int
         atomicCAS(info, 0, col0 + bad);  //          until oisat_solve_status clears them
         atomicCAS(info + 1, 0, col0 + bad);
         atomicAdd(info + 2, 1);
+        atomicCAS(info + 3, 0, (int)blockIdx.x + 1);   // batched factorization: which matrix of the table (1-based)
     }
     if (lane < 16) {                      // L: lower part of row r (the upper part of the block now belongs to X^T)
 #pragma unroll
@@ -395,8 +476,15 @@ __device__ __forceinline__ void diag16_factor_invert(float* a, float* tdiag, int
 }
 
 __global__ __launch_bounds__(256) void potrf_diag_kernel(float* __restrict__ S, int64_t ld, int64_t k0, float* __restrict__ tinv,
-                                                          int* __restrict__ info, int block_index) {
+                                                          int* __restrict__ info, int block_index, const BatchMat* __restrict__ mats) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    if (mats) {                            // batched: workgroup = matrix blockIdx.x of the table (largest first)
+        const BatchMat bm = mats[blockIdx.x];
+        if (block_index >= bm.mpb) return;
+        S = bm.S;
+        ld = bm.ld;
+        tinv = bm.tinv;
+    }
     float* a = sm;                         // [128][LDA]: L below/on the diagonal, T^T above it
     float* tdiag = sm + NB * LDA;          // [128]: diagonal of T
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -799,20 +887,97 @@ int launch_gemm(oisat_ctx* h, const char* name, float* C, int64_t ldc, const flo
     if (ntiles <= small_max && h->small_tiles && C != A) {
         const int sm = (int)(M / SB), sn = (int)(N / SB);
         const int64_t st = lower ? (int64_t)sn * sm - (int64_t)sn * (sn - 1) / 2 : (int64_t)sm * sn;
-        OISAT_LAUNCH(h, name, gemm_nt_small_kernel, dim3((unsigned)st), dim3(256), 0, C, ldc, A, lda, B, ldb, sm, sn, K, mode, lower);
+        OISAT_LAUNCH(h, name, gemm_nt_small_kernel<false>, dim3((unsigned)st), dim3(256), 0, C, ldc, A, lda, B, ldb, sm, sn, K, mode, lower,
+                     BatchArgs{});
         return OISAT_OK;
     }
     if (ntiles <= small_max && h->small_tiles && C == A && N == NB && !lower) {     // in-place TRSM-as-GEMM
-        OISAT_LAUNCH(h, name, gemm_nt_rows64_kernel, dim3((unsigned)(M / SB)), dim3(256), 0, C, ldc, A, lda, B, ldb, K, mode);
+        OISAT_LAUNCH(h, name, gemm_nt_rows64_kernel<false>, dim3((unsigned)(M / SB)), dim3(256), 0, C, ldc, A, lda, B, ldb, K, mode,
+                     BatchArgs{});
         return OISAT_OK;
     }
     if (ntiles >= (int64_t)INT32_MAX) {
         oisat_set_error("gemm grid too large");
         return OISAT_EINVAL;
     }
-    OISAT_LAUNCH(h, name, gemm_nt_kernel, dim3((unsigned)ntiles), dim3(256), 0, C, ldc, A, lda, B, ldb, ntm, ntn, K, mode, lower,
-                 (int)ntiles);
+    OISAT_LAUNCH(h, name, gemm_nt_kernel<false>, dim3((unsigned)ntiles), dim3(256), 0, C, ldc, A, lda, B, ldb, ntm, ntn, K, mode, lower,
+                 (int)ntiles, BatchArgs{});
     return OISAT_OK;
+}
+
+// ---- batched recursion: the same tree as potrf_rec over the block range of the LARGEST matrix; a node applies to the
+// matrices that reach it (a prefix of the table), every launch covers all of them ------------------------------------------
+static inline int64_t tiles_lower(int64_t ntm, int64_t ntn) { return ntn * ntm - ntn * (ntn - 1) / 2; }
+
+int launch_gemm_batched(oisat_ctx* h, const char* name, const ChBatch& bt, BatchArgs ba, int K, int mode, int lower) {
+    // participants and tile counts (units of 128) from the host copy of the table
+    int cnt = 0;
+    int64_t sum = 0, mx = 0;
+    for (const BatchMat& m : bt.table) {
+        int64_t rows, cols;
+        if (ba.kind == 0) { rows = m.mpb - ba.mid; cols = (ba.b1 < m.mpb ? ba.b1 : m.mpb) - ba.mid; }
+        else { rows = m.mpb - ba.b0 - 1; cols = 1; }
+        if (rows <= 0 || cols <= 0) break;                  // sorted: nobody further down reaches this node either
+        const int64_t t = lower ? tiles_lower(rows, cols) : rows * cols;
+        sum += t;
+        if (t > mx) mx = t;
+        ++cnt;
+    }
+    if (cnt == 0) return OISAT_OK;
+    static const int small_max = getenv("OISAT_SMALL_TILES") ? atoi(getenv("OISAT_SMALL_TILES")) : 700;
+    const BatchMat& big = bt.table[0];
+    if (ba.kind == 1) {                                     // in-place TRSM: whole rows per workgroup
+        const int64_t rows = big.mpb - ba.b0 - 1;
+        if (sum <= small_max) {
+            OISAT_LAUNCH(h, name, gemm_nt_rows64_kernel<true>, dim3((unsigned)(rows * 2), (unsigned)cnt), dim3(256), 0, (float*)nullptr,
+                         (int64_t)0, (const float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0, K, mode, ba);
+        } else {
+            OISAT_LAUNCH(h, name, gemm_nt_kernel<true>, dim3((unsigned)rows, (unsigned)cnt), dim3(256), 0, (float*)nullptr, (int64_t)0,
+                         (const float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0, 0, 0, K, mode, 0, 0, ba);
+        }
+        return OISAT_OK;
+    }
+    const int64_t rows = big.mpb - ba.mid, cols = (ba.b1 < big.mpb ? ba.b1 : big.mpb) - ba.mid;
+    if (sum <= small_max) {
+        const int64_t st = lower ? tiles_lower(rows * 2, cols * 2) : rows * cols * 4;
+        OISAT_LAUNCH(h, name, gemm_nt_small_kernel<true>, dim3((unsigned)st, (unsigned)cnt), dim3(256), 0, (float*)nullptr, (int64_t)0,
+                     (const float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0, 0, 0, K, mode, lower, ba);
+    } else {
+        OISAT_LAUNCH(h, name, gemm_nt_kernel<true>, dim3((unsigned)mx, (unsigned)cnt), dim3(256), 0, (float*)nullptr, (int64_t)0,
+                     (const float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0, 0, 0, K, mode, lower, 0, ba);
+    }
+    return OISAT_OK;
+}
+
+int potrf_rec_batched(oisat_ctx* h, const ChBatch& bt, int b0, int b1, int* info_dev) {
+    if (b1 - b0 == 1) {
+        int cnt = 0;
+        for (const BatchMat& m : bt.table) {
+            if (m.mpb <= b0) break;
+            ++cnt;
+        }
+        if (cnt == 0) return OISAT_OK;
+        OISAT_LAUNCH(h, "potrf_diag", potrf_diag_kernel, dim3((unsigned)cnt), dim3(256), kDiagShm, (float*)nullptr, (int64_t)0,
+                     (int64_t)b0 * NB, (float*)nullptr, info_dev, b0, (const BatchMat*)bt.table_dev);
+        return launch_gemm_batched(h, "trsm_gemm", bt, BatchArgs{bt.table_dev, 1, b0, 0, 0}, NB, 1, 0);
+    }
+    const int mid = b0 + (b1 - b0 + 1) / 2;
+    int rc = potrf_rec_batched(h, bt, b0, mid, info_dev);
+    if (rc) return rc;
+    rc = launch_gemm_batched(h, "syrk_gemm", bt, BatchArgs{bt.table_dev, 0, b0, mid, b1}, (mid - b0) * NB, 0, 1);
+    if (rc) return rc;
+    return potrf_rec_batched(h, bt, mid, b1, info_dev);
+}
+
+__global__ __launch_bounds__(256) void pad_identity_batched_kernel(const BatchMat* __restrict__ mats) {
+    const BatchMat m = mats[blockIdx.y];
+    const int64_t mp = (int64_t)m.mpb * NB;
+    const int64_t total = (mp - m.m) * mp;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += stride) {
+        const int64_t r = m.m + p / mp, c = p % mp;
+        m.S[r * m.ld + c] = r == c ? 1.f : 0.f;
+    }
 }
 
 // factor block columns [b0, b1) (units of NB) given that everything to their left is applied
@@ -820,7 +985,8 @@ int potrf_rec(oisat_ctx* h, float* S, int64_t ld, int64_t mpb, int64_t b0, int64
     if (b1 - b0 == 1) {
         const int64_t k0 = b0 * NB;
         const size_t shm = kDiagShm;
-        OISAT_LAUNCH(h, "potrf_diag", potrf_diag_kernel, dim3(1), dim3(256), shm, S, ld, k0, tinv, info_dev, (int)b0);
+        OISAT_LAUNCH(h, "potrf_diag", potrf_diag_kernel, dim3(1), dim3(256), shm, S, ld, k0, tinv, info_dev, (int)b0,
+                     (const BatchMat*)nullptr);
         const int64_t rows = (mpb - b0 - 1) * NB;
         if (rows > 0) {
             float* P = S + (k0 + NB) * ld + k0;                  // panel below the diagonal block
@@ -975,6 +1141,22 @@ int trsm_rows_rec(oisat_ctx* h, const ChFactor& f, float* X, int64_t nrows, int6
     return trsm_rows_rec(h, f, X, nrows, ldx, mid, b1);
 }
 
+// per-function attributes, set once per process (handles may be driven from different host threads)
+hipError_t dense_kernel_attributes() {
+    static const hipError_t attr_rc = []() {
+        hipError_t e = hipFuncSetAttribute((const void*)potrf_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)kDiagShm);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)trsv_pipe_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(sizeof(float) * NB * TLD));
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)trsv_pipe_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(sizeof(float) * NB * TLD));
+        return e;
+    }();
+    return attr_rc;
+}
+
 }  // namespace
 
 extern "C" int oisat_gemm_nt(oisat_ctx* h, float* C, int64_t ldc, const float* A, int64_t lda, const float* B, int64_t ldb,
@@ -996,19 +1178,7 @@ extern "C" int oisat_potrf(oisat_ctx* h, float* S, int64_t m, int64_t ld, int* i
     int* info_dev = nullptr;
     if (!tinv) return OISAT_ENOMEM;
     if (int rc = status_ws(h, &info_dev, nullptr)) return rc;
-    // per-function attributes, set once per process (handles may be driven from different host threads)
-    static const hipError_t attr_rc = []() {
-        hipError_t e = hipFuncSetAttribute((const void*)potrf_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)kDiagShm);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)trsv_pipe_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)(sizeof(float) * NB * TLD));
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)trsv_pipe_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)(sizeof(float) * NB * TLD));
-        return e;
-    }();
-    HIP_TRY(attr_rc);
+    HIP_TRY(dense_kernel_attributes());
     HIP_TRY(hipMemsetAsync(info_dev, 0, sizeof(int), h->stream));      // info[0] only: the sticky words survive
     if (mp > m) {
         OISAT_LAUNCH(h, "pad_identity", pad_identity_kernel, dim3(stream_grid((mp - m) * mp, 256)), dim3(256), 0, S, ld, m, mp);
@@ -1210,5 +1380,101 @@ extern "C" int oisat_dense_reserve(oisat_ctx* h, int64_t max_obs, int64_t diag_c
     }
     if (!oisat_ws(h, 6, s6)) return OISAT_ENOMEM;
     if (!oisat_pinned(h, 4096)) return OISAT_ENOMEM;
+    return OISAT_OK;
+}
+
+// ---- batched factorization ---------------------------------------------------------------------------------------
+extern "C" int oisat_batch_create(oisat_ctx* h, int nmat, float* const* S, const int64_t* m, const int64_t* ld, float* const* tinv,
+                                  int* batch_id_out) {
+    ARG_CHECK(h && S && m && ld && tinv && batch_id_out && nmat > 0 && nmat <= 65535);
+    ChBatch* bt = new ChBatch();
+    bt->order.resize(nmat);
+    for (int i = 0; i < nmat; ++i) bt->order[i] = i;
+    for (int i = 0; i < nmat; ++i) {
+        const int64_t mp = cdiv(m[i], NB) * NB;
+        if (!(S[i] && tinv[i] && m[i] > 0 && ld[i] >= mp && (ld[i] % 4) == 0 && ((uintptr_t)S[i] % 16) == 0 && ((uintptr_t)tinv[i] % 16) == 0 &&
+              mp / NB < (int64_t)INT32_MAX)) {
+            delete bt;
+            oisat_set_error("oisat_batch_create: matrix %d: bad pointer, size or leading dimension", i);
+            return OISAT_EINVAL;
+        }
+    }
+    // largest first (stable): the matrices a node of the recursion applies to are then a prefix of the table
+    std::stable_sort(bt->order.begin(), bt->order.end(), [&](int a, int b) { return cdiv(m[a], NB) > cdiv(m[b], NB); });
+    bt->table.resize(nmat);
+    for (int i = 0; i < nmat; ++i) {
+        const int k = bt->order[i];
+        bt->table[i] = BatchMat{S[k], tinv[k], ld[k], m[k], (int)cdiv(m[k], NB), 0};
+    }
+    bt->max_mpb = bt->table[0].mpb;
+    if (hipMalloc(&bt->table_dev, sizeof(BatchMat) * nmat) != hipSuccess) {
+        delete bt;
+        oisat_set_error("oisat_batch_create: hipMalloc of the table failed");
+        return OISAT_ENOMEM;
+    }
+    if (hipMemcpy(bt->table_dev, bt->table.data(), sizeof(BatchMat) * nmat, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(bt->table_dev);
+        delete bt;
+        oisat_set_error("oisat_batch_create: upload of the table failed");
+        return OISAT_EHIP;
+    }
+    int id = -1;
+    for (size_t i = 0; i < h->batches.size(); ++i)
+        if (!h->batches[i]) { id = (int)i; break; }
+    if (id < 0) { h->batches.push_back(nullptr); id = (int)h->batches.size() - 1; }
+    h->batches[id] = bt;
+    *batch_id_out = id;
+    return OISAT_OK;
+}
+
+extern "C" int oisat_batch_destroy(oisat_ctx* h, int batch_id) {
+    ARG_CHECK(h && batch_id >= 0 && batch_id < (int)h->batches.size() && h->batches[batch_id]);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    ChBatch* bt = h->batches[batch_id];
+    if (bt->table_dev) HIP_TRY(hipFree(bt->table_dev));
+    delete bt;
+    h->batches[batch_id] = nullptr;
+    return OISAT_OK;
+}
+
+extern "C" int oisat_batch_potrf(oisat_ctx* h, int batch_id, int* info_host) {
+    ARG_CHECK(h && batch_id >= 0 && batch_id < (int)h->batches.size() && h->batches[batch_id]);
+    const ChBatch& bt = *h->batches[batch_id];
+    int* info_dev = nullptr;
+    if (int rc = status_ws(h, &info_dev, nullptr)) return rc;
+    HIP_TRY(dense_kernel_attributes());
+    HIP_TRY(hipMemsetAsync(info_dev, 0, sizeof(int), h->stream));
+    HIP_TRY(hipMemsetAsync(info_dev + 3, 0, sizeof(int), h->stream));
+    OISAT_LAUNCH(h, "pad_identity", pad_identity_batched_kernel, dim3(32, (unsigned)bt.table.size()), dim3(256), 0,
+                 (const BatchMat*)bt.table_dev);
+    const int rc = potrf_rec_batched(h, bt, 0, bt.max_mpb, info_dev);
+    if (rc) return rc;
+    if (info_host) {
+        int* pin = (int*)oisat_pinned(h, 64);
+        if (!pin) return OISAT_ENOMEM;
+        HIP_TRY(hipMemcpyAsync(pin, info_dev, 4 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        info_host[0] = pin[0];
+        info_host[1] = pin[0] ? bt.order[pin[3] - 1] : -1;          // the caller's matrix index
+        if (pin[0] != 0) {
+            HIP_TRY(hipMemsetAsync(info_dev + 1, 0, 2 * sizeof(int), h->stream));
+            oisat_set_error("batched potrf: matrix %d not positive definite at column %d", info_host[1], pin[0]);
+            return OISAT_ENOTPD;
+        }
+    }
+    return OISAT_OK;
+}
+
+extern "C" int oisat_factor_adopt(oisat_ctx* h, const float* L, int64_t m, int64_t ld, float* tinv) {
+    ARG_CHECK(h && L && tinv && m > 0);
+    const int64_t mp = cdiv(m, NB) * NB;
+    ARG_CHECK(ld >= mp && (ld % 4) == 0 && ((uintptr_t)L % 16) == 0 && ((uintptr_t)tinv % 16) == 0);
+    if (int rc = status_ws(h, nullptr, nullptr)) return rc;
+    HIP_TRY(dense_kernel_attributes());
+    h->factor.S = L;
+    h->factor.m = m;
+    h->factor.mp = mp;
+    h->factor.ld = ld;
+    h->factor.tinv = tinv;
     return OISAT_OK;
 }

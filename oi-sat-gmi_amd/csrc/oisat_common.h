@@ -34,6 +34,22 @@ struct ChFactor {                // what the triangular solves need besides L: t
     float* tinv = nullptr;       // [mp/128][128][128]: inverted diagonal blocks, row-major
 };
 
+struct BatchMat {                // one matrix of a batched factorization (device table entry)
+    float* S;
+    float* tinv;                 // [mpb][128][128]
+    int64_t ld;
+    int64_t m;
+    int mpb;                     // roundup(m, 128) / 128
+    int pad;
+};
+
+struct ChBatch {                 // matrices factored in lock-step by oisat_batch_potrf (sorted by block count, largest first)
+    BatchMat* table_dev = nullptr;
+    std::vector<BatchMat> table;
+    std::vector<int> order;      // table[i] is the caller's matrix order[i]
+    int max_mpb = 0;
+};
+
 struct oisat_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -58,6 +74,8 @@ struct oisat_ctx {
     hipStream_t own_stream = nullptr;   // created by oisat_stream_create, destroyed at shutdown
     hipStream_t aux_stream = nullptr;   // look-ahead Cholesky: trailing updates run here, the panel chain on `stream`
     std::vector<hipEvent_t> sync_events;
+    hipEvent_t signal_event = nullptr;  // oisat_wait_for: recorded on this handle's stream, waited on by another handle's
+    std::vector<ChBatch*> batches;      // oisat_batch_create
     // pinned host scratch for small synchronous read-backs
     void* pinned = nullptr;
     size_t pinned_bytes = 0;

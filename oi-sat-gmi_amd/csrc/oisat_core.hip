@@ -54,6 +54,12 @@ extern "C" void oisat_shutdown(oisat_ctx* h) {
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
     for (auto ev : h->sync_events) (void)hipEventDestroy(ev);
+    if (h->signal_event) (void)hipEventDestroy(h->signal_event);
+    for (auto* b : h->batches)
+        if (b) {
+            if (b->table_dev) (void)hipFree(b->table_dev);
+            delete b;
+        }
     delete h;
 }
 
@@ -81,6 +87,15 @@ extern "C" int oisat_stream_create(oisat_ctx* h) {
 extern "C" int oisat_bind_thread(oisat_ctx* h) {
     ARG_CHECK(h != nullptr);
     HIP_TRY(hipSetDevice(h->device));       // the current device is per host thread in HIP
+    return OISAT_OK;
+}
+
+extern "C" int oisat_wait_for(oisat_ctx* waiter, oisat_ctx* signaler) {
+    ARG_CHECK(waiter != nullptr && signaler != nullptr);
+    if (waiter->stream == signaler->stream) return OISAT_OK;          // same stream: already ordered
+    if (!signaler->signal_event) HIP_TRY(hipEventCreateWithFlags(&signaler->signal_event, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(signaler->signal_event, signaler->stream));
+    HIP_TRY(hipStreamWaitEvent(waiter->stream, signaler->signal_event, 0));
     return OISAT_OK;
 }
 

@@ -31,6 +31,7 @@ SIGNATURES = {
     "oisat_set_stream": (C.c_int, [_c_ctx, _ptr]),
     "oisat_stream_create": (C.c_int, [_c_ctx]),
     "oisat_bind_thread": (C.c_int, [_c_ctx]),
+    "oisat_wait_for": (C.c_int, [_c_ctx, _c_ctx]),
     "oisat_sync": (C.c_int, [_c_ctx]),
     "oisat_dmalloc": (C.c_int, [_c_ctx, C.c_size_t, C.POINTER(_ptr)]),
     "oisat_dfree": (C.c_int, [_c_ctx, _ptr]),
@@ -83,6 +84,11 @@ SIGNATURES = {
     "oisat_gain_diag": (C.c_int, [_c_ctx, _ptr, _i64, _i64, _ptr, _i64, _ptr]),
     "oisat_apply_increment": (C.c_int, [_c_ctx, C.c_int, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i64, C.c_double, _ptr,
                                         _ptr, _ptr, _ptr, _ptr]),
+    "oisat_batch_create": (C.c_int, [_c_ctx, C.c_int, C.POINTER(_ptr), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_ptr),
+                                     C.POINTER(C.c_int)]),
+    "oisat_batch_potrf": (C.c_int, [_c_ctx, C.c_int, C.POINTER(C.c_int)]),
+    "oisat_batch_destroy": (C.c_int, [_c_ctx, C.c_int]),
+    "oisat_factor_adopt": (C.c_int, [_c_ctx, _ptr, _i64, _i64, _ptr]),
     "oisat_solve_status": (C.c_int, [_c_ctx, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]),
     "oisat_dense_reserve": (C.c_int, [_c_ctx, _i64, _i64]),
 }
@@ -228,6 +234,10 @@ class Context:
     def bind_thread(self):
         """Make this handle's device the calling thread's current HIP device (per-thread state in HIP)."""
         self.check(self.lib.oisat_bind_thread(self.h))
+
+    def wait_for(self, other: "Context"):
+        """Order this handle's stream after everything enqueued so far on ``other``'s stream (device-side)."""
+        self.check(self.lib.oisat_wait_for(self.h, other.h))
 
     def sync(self):
         self.check(self.lib.oisat_sync(self.h))

@@ -56,7 +56,7 @@ class DenseAnalysis:
     ``run`` per month.  Buffers are sized at ``max_obs`` so nothing is allocated per analysis."""
 
     def __init__(self, grid_lat, grid_lon, max_obs: int, dtype=np.float32, ctx=None, shared_S=None, out_ptr=None,
-                 diag_chunk_rows: int = 0):
+                 diag_chunk_rows: int = 0, batched: bool = False):
         """``shared_S``: a factor buffer (``SharedFactor`` or device buffer) shared with other analyses that run one
         after another on the same handle.  ``out_ptr``: device address of 2 n elements where ``xa | inc`` are to be
         written (e.g. a slice of one slab that is gathered over RCCL); by default the plan owns them."""
@@ -91,6 +91,9 @@ class DenseAnalysis:
         self.S = shared_S if shared_S is not None else c.alloc(self.mp_max * self.mp_max * 4)
         if self.S.nbytes < self.mp_max * self.mp_max * 4:
             raise ValueError("shared_S is too small for max_obs")
+        # batched factorization (BatchedFactor): the inverted diagonal blocks live in a buffer of this plan, not in the
+        # handle's workspace, because many plans of one handle are factored at the same time
+        self.tinv = c.alloc(self.mp_max * NB * 4) if batched else None
         self.m = 0
         self._direct_innovation = False
         # every internal workspace of the solve is sized here, so that run() never allocates (include/oisat.h)
@@ -169,6 +172,25 @@ class DenseAnalysis:
         c.check(lib.oisat_apply_increment(h, self.code, self.gxyz.ptr, self.gsig.ptr, self.n, self.oxyz.ptr,
                                           self.osig.ptr, self.z.ptr, m, g, xb, xa, inc, self.glat.ptr, self.olat.ptr))
         return list(resid) if want_resid else None
+
+    # ---- the same pipeline in two halves, for lock-step (batched) factorization of many plans: build | factor | solve
+    def run_build(self, L_km: float):
+        c, lib, h = self.ctx, self.ctx.lib, self.ctx.h
+        g = self._g = decay_constant(L_km)
+        if not self._direct_innovation:
+            c.check(lib.oisat_innovation(h, self.code, self.xb_ptr, self.ocell.ptr, self.oy.ptr, self.m, self.d.ptr))
+        c.check(lib.oisat_cov_build(h, self.oxyz.ptr, self.osig.ptr, self.ovar.ptr, self.m, g, self.S.ptr, self.mp))
+
+    def run_solve(self, refine: int = 2):
+        c, lib, h = self.ctx, self.ctx.lib, self.ctx.h
+        m, ld, g = self.m, self.mp, self._g
+        item = self.dt.itemsize
+        xb, xa, inc = self.xb_ptr, self.out_ptr, self.out_ptr + self.n * item
+        c.check(lib.oisat_factor_adopt(h, self.S.ptr, m, ld, self.tinv.ptr))
+        c.check(lib.oisat_gain_solve(h, self.S.ptr, self.oxyz.ptr, self.osig.ptr, self.ovar.ptr, m, ld, g, self.d.ptr,
+                                     int(refine), self.z.ptr, None, self.olat.ptr))
+        c.check(lib.oisat_apply_increment(h, self.code, self.gxyz.ptr, self.gsig.ptr, self.n, self.oxyz.ptr,
+                                          self.osig.ptr, self.z.ptr, m, g, xb, xa, inc, self.glat.ptr, self.olat.ptr))
 
     # ---- posterior diagnostics (after run(); they reuse the factor that run() left in HBM)
     def posterior_error(self, chunk_rows: int = 4096):
@@ -250,6 +272,63 @@ def tile_partition(lat2, lon2, obs_lat, obs_lon, tile_deg=30.0, halo_km=900.0, m
             sel = np.flatnonzero(in_lat & (dl <= half))
             tiles.append({"rows": (y0, y1), "cols": (x0, x1), "obs": sel})
     return tiles
+
+
+class BatchedFactor:
+    """Lock-step factorization of many plans (``oisat_batch_potrf``): the plans are sorted by size and cut into groups of
+    comparable block count (a group's smallest matrix has at least ``ratio`` of the blocks of its largest), one batch and
+    one stream per group -- in a 720x1440 month: the two polar caps (137 blocks) and the 48 mid-latitude tiles (31-48)."""
+
+    def __init__(self, device: int, plans, ratio: float = 0.5):
+        self.groups = []
+        order = sorted((p for p in plans if p is not None), key=lambda p: -p.m)
+        cur = []
+        for p in order:
+            if cur and p.mp < ratio * cur[0].mp:
+                self.groups.append(cur)
+                cur = []
+            cur.append(p)
+        if cur:
+            self.groups.append(cur)
+        self.ctxs, self.ids = [], []
+        for g in self.groups:
+            ctx = _hip.Context(device).own_stream()
+            n = len(g)
+            Sp = (C.c_void_p * n)(*[p.S.ptr for p in g])
+            Tp = (C.c_void_p * n)(*[p.tinv.ptr for p in g])
+            mm = (C.c_int64 * n)(*[p.m for p in g])
+            ld = (C.c_int64 * n)(*[p.mp for p in g])
+            bid = C.c_int(-1)
+            ctx.check(ctx.lib.oisat_batch_create(ctx.h, n, Sp, mm, ld, Tp, C.byref(bid)))
+            self.ctxs.append(ctx)
+            self.ids.append(bid.value)
+
+    def factor(self, check_pd=False):
+        """Every group's stream waits for the lanes that built its matrices, factors them, and the lanes wait for it."""
+        for g, ctx, bid in zip(self.groups, self.ctxs, self.ids):
+            lanes = list({id(p.ctx): p.ctx for p in g}.values())
+            for lane in lanes:
+                ctx.wait_for(lane)
+            info = (C.c_int * 2)(0, -1)
+            ctx.check(ctx.lib.oisat_batch_potrf(ctx.h, bid, info if check_pd else None))
+            for lane in lanes:
+                lane.wait_for(ctx)
+
+    def check(self, what="batched factorization"):
+        errors = []
+        for ctx in self.ctxs:
+            try:
+                ctx.check_solves(what)
+            except _hip.OisatError as e:
+                errors.append(str(e))
+        if errors:
+            raise _hip.OisatError("; ".join(errors))
+
+    def close(self):
+        for ctx, bid in zip(self.ctxs, self.ids):
+            ctx.lib.oisat_batch_destroy(ctx.h, bid)
+            ctx.close()
+        self.ctxs, self.ids = [], []
 
 
 class SharedFactor:
@@ -351,6 +430,20 @@ class LanePool:
             lane.close()
 
 
+def _check_all(what, *checkers):
+    """Run every status check (each waits for its streams and clears what it reports), then raise once."""
+    errors = []
+    for c in checkers:
+        if c is None:
+            continue
+        try:
+            c.check(what)
+        except _hip.OisatError as e:
+            errors.append(str(e))
+    if errors:
+        raise _hip.OisatError("; ".join(errors))
+
+
 class TiledAnalysis:
     """Localised block-B analysis: one small dense analysis per tile (its own S = H B H^T + R over the
     tile's observations + halo).  Tiles are independent work units: inside one GPU they are dealt to the lanes of a
@@ -358,8 +451,15 @@ class TiledAnalysis:
     ``parallel.shard_units`` spreads (month x tile) units -- ``only`` restricts this object to the tiles a rank owns."""
 
     def __init__(self, grid_lat, grid_lon, tile_deg=30.0, halo_km=900.0, dtype=np.float32, ctx=None, streams=12, pool=None,
-                 merge_polar=True):
+                 merge_polar=True, batched=True):
+        """``batched`` (default): every tile keeps its own S and all tiles are factored in lock-step by
+        ``oisat_batch_potrf`` (one launch per recursion node for all tiles) between a per-lane build phase and a per-lane
+        solve phase; ``batched=False``: each lane runs its tiles' whole pipelines back to back with one shared factor
+        buffer (less memory: one S per lane instead of one per tile)."""
         self.merge_polar = bool(merge_polar)
+        self.batched = bool(batched)
+        self.factor = None
+        self._own_pool = pool is None
         self.pool = pool or LanePool(ctx, streams)
         self.ctx = self.pool.ctx
         self.lanes = self.pool.lanes
@@ -393,23 +493,26 @@ class TiledAnalysis:
         self.flops = sum(DenseAnalysis.flops(int(self.tiles[ti]["obs"].size)) for ti in self.live)
         return self.live, [int(self.tiles[ti]["obs"].size) for ti in self.live]
 
-    def build(self, lane_of=None, order=None, out_ptrs=None):
+    def build(self, lane_of=None, order=None, out_ptrs=None, group=True):
         """Device side: one plan per live tile on its lane.  ``lane_of`` / ``order``: per live tile (default: LPT by
-        obs^3 over this object's tiles alone); ``out_ptrs``: per live tile, where its ``xa | inc`` go."""
+        obs^3 over this object's tiles alone); ``out_ptrs``: per live tile, where its ``xa | inc`` go; ``group``: form
+        this object's own ``BatchedFactor`` (False when a ``MonthTileBatch`` groups the plans of several months)."""
         h = self._host
         sizes = [int(self.tiles[ti]["obs"].size) for ti in self.live]
         if lane_of is None:
-            lane_of, order = self.pool.assign([float(m) ** 3 for m in sizes])
-        for k, m in enumerate(sizes):
-            self.pool.factors[lane_of[k]].reserve(m)
+            # batched: the factorization is not a lane's job, what is left per tile grows like m^2 (solves) + n m
+            lane_of, order = self.pool.assign([float(m) ** (2 if self.batched else 3) for m in sizes])
+        if not self.batched:
+            for k, m in enumerate(sizes):
+                self.pool.factors[lane_of[k]].reserve(m)
         self.plans = [None] * len(self.tiles)
         for k, ti in enumerate(self.live):
             t = self.tiles[ti]
             (y0, y1), (x0, x1) = t["rows"], t["cols"]
             li = lane_of[k]
             p = DenseAnalysis(self.lat2[y0:y1, x0:x1], self.lon2[y0:y1, x0:x1], max_obs=sizes[k], dtype=self.dt,
-                              ctx=self.lanes[li], shared_S=self.pool.factors[li],
-                              out_ptr=None if out_ptrs is None else out_ptrs[k])
+                              ctx=self.lanes[li], shared_S=None if self.batched else self.pool.factors[li],
+                              out_ptr=None if out_ptrs is None else out_ptrs[k], batched=self.batched)
             p.load_background(h["Xa"][y0:y1, x0:x1], h["Sa"][y0:y1, x0:x1], scale=h["scale"])
             o = t["obs"]
             p.load_obs_direct(h["olat"][o], h["olon"][o], h["s"][o], h["ovar"][o], h["d"][o])
@@ -417,16 +520,29 @@ class TiledAnalysis:
         self._order = [self.live[k] for k in (order if order is not None else range(len(self.live)))]
         self._lane_of = {ti: lane_of[k] for k, ti in enumerate(self.live)}
         self._host = None
+        if self.factor is not None:
+            self.factor.close()
+            self.factor = None
+        if self.batched and group and self.live:
+            self.factor = BatchedFactor(self.ctx.device, [self.plans[ti] for ti in self.live])
 
     def load(self, Xa, Sa, obs_lat, obs_lon, obs_y, obs_var, scale=1.0, only=None):
         self.prepare(Xa, Sa, obs_lat, obs_lon, obs_y, obs_var, scale=scale, only=only)
         self.build()
 
-    def enqueue(self, L_km, refine=1, check_pd=False):
+    def _per_lane(self, fn):
         per_lane = [[] for _ in self.lanes]
         for ti in self._order:                           # run order (heaviest first) is kept inside every lane
-            per_lane[self._lane_of[ti]].append(lambda p=self.plans[ti]: p.run(L_km, refine=refine, check_pd=check_pd))
-        self.pool.enqueue(per_lane)
+            per_lane[self._lane_of[ti]].append(lambda p=self.plans[ti]: fn(p))
+        return per_lane
+
+    def enqueue(self, L_km, refine=1, check_pd=False):
+        if not self.batched:
+            self.pool.enqueue(self._per_lane(lambda p: p.run(L_km, refine=refine, check_pd=check_pd)))
+            return
+        self.pool.enqueue(self._per_lane(lambda p: p.run_build(L_km)))         # innovation, S = H B H^T + R
+        self.factor.factor(check_pd=check_pd)                                   # all tiles in lock-step
+        self.pool.enqueue(self._per_lane(lambda p: p.run_solve(refine)))        # gain solve, increment
 
     def run(self, L_km, refine=1, check_pd=False):
         """Enqueue every tile on its lane's stream (largest first), wait for all lanes and check their solve status:
@@ -434,7 +550,16 @@ class TiledAnalysis:
         self.ctx.sync()                                 # inputs uploaded on the default stream are complete
         self._L, self._refine = float(L_km), int(refine)
         self.enqueue(L_km, refine=refine, check_pd=check_pd)
-        self.pool.check("tiled analysis")
+        _check_all("tiled analysis", self.pool, self.factor)
+
+    def close(self):
+        """Release the batch streams / tables and the lane pool (if this object made it)."""
+        if self.factor is not None:
+            self.factor.close()
+            self.factor = None
+        self.plans = []
+        if self._own_pool:
+            self.pool.close()
 
     def download(self):
         """(xa, inc) on the full grid; cells of tiles this object does not own keep the background / zero."""
@@ -458,7 +583,10 @@ class TiledAnalysis:
         for ti in self._order:
             t, p = self.tiles[ti], self.plans[ti]
             (y0, y1), (x0, x1) = t["rows"], t["cols"]
-            p.run(self._L, refine=self._refine, check_pd=True)
+            if self.batched:                             # every tile still holds its own factor: adopt, do not redo
+                p.ctx.check(p.ctx.lib.oisat_factor_adopt(p.ctx.h, p.S.ptr, p.m, p.mp, p.tinv.ptr))
+            else:
+                p.run(self._L, refine=self._refine, check_pd=True)
             err[y0:y1, x0:x1] = p.posterior_error(chunk_rows)
             a = p.gain_diag(chunk_rows)
             inside = self._inside[ti]                    # halo observations belong to another tile's cells
@@ -473,8 +601,10 @@ class MonthTileBatch:
     ``parallel`` gathers to rank 0 in a single message.  (Reference: one scheduler job per month,
     run/job_submitter_sbatch.py:45-68; months alone cap 8 GPUs at 12/2 = 6x, hence the finer unit.)"""
 
-    def __init__(self, grid_lat, grid_lon, tile_deg=30.0, halo_km=900.0, dtype=np.float32, ctx=None, streams=12):
+    def __init__(self, grid_lat, grid_lon, tile_deg=30.0, halo_km=900.0, dtype=np.float32, ctx=None, streams=12, batched=True):
         self.pool = LanePool(ctx, streams)
+        self.batched = bool(batched)
+        self.factor = None
         self.ctx = self.pool.ctx
         self.lat2, self.lon2 = np.asarray(grid_lat), np.asarray(grid_lon)
         self.tile_deg, self.halo_km, self.dt = float(tile_deg), float(halo_km), np.dtype(dtype)
@@ -482,16 +612,17 @@ class MonthTileBatch:
         self.units = []                                 # (month key, tile index, nobs) in insertion order
 
     def add_month(self, key, Xa, Sa, obs_lat, obs_lon, obs_y, obs_var, scale=1.0, only=None):
-        ta = TiledAnalysis(self.lat2, self.lon2, self.tile_deg, self.halo_km, self.dt, pool=self.pool)
+        ta = TiledAnalysis(self.lat2, self.lon2, self.tile_deg, self.halo_km, self.dt, pool=self.pool, batched=self.batched)
         live, sizes = ta.prepare(Xa, Sa, obs_lat, obs_lon, obs_y, obs_var, scale=scale, only=only)
         self.months[key] = ta
         self.units += [(key, ti, m) for ti, m in zip(live, sizes)]
 
     def build(self, min_slab_elems: int = 0):
         item = self.dt.itemsize
-        lane_of, order = self.pool.assign([float(m) ** 3 for (_, _, m) in self.units])
-        for li, (_, _, m) in zip(lane_of, self.units):
-            self.pool.factors[li].reserve(m)
+        lane_of, order = self.pool.assign([float(m) ** (2 if self.batched else 3) for (_, _, m) in self.units])
+        if not self.batched:
+            for li, (_, _, m) in zip(lane_of, self.units):
+                self.pool.factors[li].reserve(m)
         self.offsets, total = [], 0                      # element offset of each unit's xa|inc inside the slab
         for key, ti, _ in self.units:
             (y0, y1), (x0, x1) = self.months[key].tiles[ti]["rows"], self.months[key].tiles[ti]["cols"]
@@ -504,20 +635,32 @@ class MonthTileBatch:
         for key, ta in self.months.items():              # units of one month are contiguous in self.units
             nk = len(ta.live)
             ta.build(lane_of=lane_of[k0:k0 + nk], order=None,
-                     out_ptrs=[self.slab.at(self.offsets[k] * item) for k in range(k0, k0 + nk)])
+                     out_ptrs=[self.slab.at(self.offsets[k] * item) for k in range(k0, k0 + nk)], group=False)
             k0 += nk
+        if self.batched and self.units:                  # one lock-step factorization over the units of ALL months
+            self.factor = BatchedFactor(self.ctx.device, [self.months[key].plans[ti] for key, ti, _ in self.units])
         self._run_order = [self.units[i][:2] for i in order]
         self.flops = sum(ta.flops for ta in self.months.values())
 
     def run(self, L_km, refine=1, check_pd=False, wait=True):
         self.ctx.sync()
-        per_lane = [[] for _ in self.pool.lanes]
-        for key, ti in self._run_order:                  # heaviest unit first, across months
-            ta = self.months[key]
-            per_lane[ta._lane_of[ti]].append(lambda p=ta.plans[ti]: p.run(L_km, refine=refine, check_pd=check_pd))
-        self.pool.enqueue(per_lane)
+        def per_lane(fn):
+            out = [[] for _ in self.pool.lanes]
+            for key, ti in self._run_order:              # heaviest unit first, across months
+                ta = self.months[key]
+                out[ta._lane_of[ti]].append(lambda p=ta.plans[ti]: fn(p))
+            return out
+        if self.batched:
+            self.pool.enqueue(per_lane(lambda p: p.run_build(L_km)))
+            self.factor.factor(check_pd=check_pd)
+            self.pool.enqueue(per_lane(lambda p: p.run_solve(refine)))
+        else:
+            self.pool.enqueue(per_lane(lambda p: p.run(L_km, refine=refine, check_pd=check_pd)))
         if wait:
-            self.pool.check("month x tile batch")
+            self.check()
+
+    def check(self):
+        _check_all("month x tile batch", self.pool, self.factor)
 
     def unit_shape(self, k):
         key, ti, _ = self.units[k]
@@ -528,6 +671,11 @@ class MonthTileBatch:
         return self.ctx.download(self.slab.ptr, (self.slab_elems,), self.dt)
 
     def close(self):
+        if self.factor is not None:
+            self.factor.close()
+            self.factor = None
+        for ta in self.months.values():
+            ta.plans = []
         self.pool.close()
 
 
@@ -614,7 +762,7 @@ def OI_tiled(Xa, Y, Sa, So, lat, lon, L_km, tile_deg=30.0, halo_km=None, scale=1
             akf[cell] = ak.ravel()[cell]
             extra = {"ak": akf.reshape(np.shape(Xa)), "err": err}
     finally:
-        ta.pool.close()
+        ta.close()
     bad = ~np.isfinite(Xa)
     if bad.any():
         xb = xb.copy()

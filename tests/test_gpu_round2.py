@@ -10,6 +10,7 @@
 
 Tolerances: float64 regridding vs the reference 1e-12; dense analysis 1e-5 of the field scale (BASELINE north star).
 """
+import ctypes as C
 import os
 
 import numpy as np
@@ -227,7 +228,7 @@ def test_tiled_config3_full_size_properties(ctx):
     assert worst_r <= 1e-6, worst_r
     assert worst_i <= 1e-5, worst_i
     assert np.abs(xa.ravel()[cell] - y).mean() < 0.8 * np.abs(p.Xa.ravel()[cell] - y).mean()
-    ta.pool.close()
+    ta.close()
 
 
 @pytest.mark.parametrize("species", ["HCHO", "O3"])
@@ -266,14 +267,16 @@ def test_dense_config5_full_size_properties(ctx, species):
 # ------------------------------------------------------------------------------------------------
 # (month x tile) batches and unchecked asynchronous solves
 # ------------------------------------------------------------------------------------------------
-def test_month_tile_batch_equals_per_month_tiled_analysis(ctx):
+@pytest.mark.parametrize("batched", [False, True])
+def test_month_tile_batch_equals_per_month_tiled_analysis(ctx, batched):
     """A batch holding an arbitrary subset of the (month x tile) units of three months writes, for every unit it owns,
-    exactly the tile the month's own TiledAnalysis produces (bitwise: the lane a tile runs on does not matter)."""
+    the tile the month's own TiledAnalysis produces -- bitwise with lane-serial factorizations (the lane a tile runs on
+    does not matter), to refinement accuracy with lock-step ones (the batch's recursion tree depends on its largest member)."""
     ny, nx, L = 36, 72, 400.0
     lat, lon = syn.global_grid(ny, nx)
     months = {k: syn.point_obs_case(ny, nx, 700 + 100 * k, 8100 + k) for k in range(3)}
     owned = {0: [0, 3, 4, 7], 1: [5], 2: [1, 2, 6]}            # tiles: 0 = south cap, 1..6 = middle band, 7 = north cap
-    batch = dense.MonthTileBatch(lat, lon, tile_deg=60.0, halo_km=3 * L, dtype=np.float32, streams=4)
+    batch = dense.MonthTileBatch(lat, lon, tile_deg=60.0, halo_km=3 * L, dtype=np.float32, streams=4, batched=batched)
     for k, p in months.items():
         batch.add_month(k, p.Xa, p.Sa, p.obs_lat, p.obs_lon, p.obs_y, p.obs_var, only=owned[k])
     batch.build()
@@ -281,19 +284,20 @@ def test_month_tile_batch_equals_per_month_tiled_analysis(ctx):
     batch.run(L, refine=2, check_pd=True)
     slab = batch.download_slab()
     for k, p in months.items():
-        ta = dense.TiledAnalysis(lat, lon, tile_deg=60.0, halo_km=3 * L, dtype=np.float32, streams=3)
+        ta = dense.TiledAnalysis(lat, lon, tile_deg=60.0, halo_km=3 * L, dtype=np.float32, streams=3, batched=batched)
         ta.load(p.Xa, p.Sa, p.obs_lat, p.obs_lon, p.obs_y, p.obs_var)
         ta.run(L, refine=2)
         xa, inc = ta.download()
-        ta.pool.close()
+        ta.close()
+        tol = 2e-6 * np.abs(p.Xa).max() if batched else 0.0
         for u, (key, ti, _) in enumerate(batch.units):
             if key != k:
                 continue
             (y0, y1), (x0, x1) = ta.tiles[ti]["rows"], ta.tiles[ti]["cols"]
             shape = batch.unit_shape(u)
             got = slab[batch.offsets[u]: batch.offsets[u] + int(np.prod(shape))].reshape(shape)
-            np.testing.assert_array_equal(got[0], xa[y0:y1, x0:x1])
-            np.testing.assert_array_equal(got[1], inc[y0:y1, x0:x1])
+            np.testing.assert_allclose(got[0], xa[y0:y1, x0:x1], rtol=0, atol=tol)
+            np.testing.assert_allclose(got[1], inc[y0:y1, x0:x1], rtol=0, atol=tol)
     batch.close()
 
 
@@ -326,7 +330,7 @@ def test_unchecked_runs_cannot_fail_silently(ctx):
         ta.run(500.0, refine=1)
     ta.load(p.Xa, p.Sa, p.obs_lat, p.obs_lon, p.obs_y, p.obs_var)
     ta.run(500.0, refine=1)
-    ta.pool.close()
+    ta.close()
 
 
 def test_gain_diag_aggregates_observations_that_share_a_cell(ctx):
@@ -383,3 +387,91 @@ def test_linear_interpolation_survives_degenerate_simplices(ctx, golden):
         off = ~(np.abs(got - g["out"]) <= RT64 * np.abs(g["out"])) & ~np.isnan(got)
     assert off.sum() <= 3, int(off.sum())
     assert np.abs(got[off] - g["out"][off]).max(initial=0.0) <= 1e-3 * np.nanmax(np.abs(g["out"]))
+
+
+def test_batched_factorization_is_bit_identical(ctx):
+    """oisat_batch_potrf: matrices of different sizes advanced through one recursion in lock-step (one launch per node
+    for all of them).  The recursion tree is the LARGEST matrix's, so that matrix's factor equals oisat_potrf's bit for
+    bit; a smaller one meets its trailing updates in a different association (different split points) and agrees to fp32
+    rounding.  A non-positive-definite member is reported with its index."""
+    lib = ctx.lib
+    sizes = [777, 300, 1500, 129, 128, 1000, 2100]
+    mats, refs = [], []
+    for k, m in enumerate(sizes):
+        p = syn.point_obs_case(72, 144, m, 9000 + k)
+        cell = dense.regular_grid_cell(p.lat, p.lon, p.obs_lat, p.obs_lon)
+        mp = -(-m // 128) * 128
+        oxyz = ctx.upload(dense.unit_vectors(p.obs_lat, p.obs_lon))
+        osig = ctx.upload(np.sqrt(p.Sa.ravel())[cell], dtype=np.float64)
+        ovar = ctx.upload(p.obs_var, dtype=np.float64)
+        S1, S2 = ctx.alloc(mp * mp * 4), ctx.alloc(mp * mp * 4)
+        for S in (S1, S2):
+            ctx.check(lib.oisat_cov_build(ctx.h, oxyz.ptr, osig.ptr, ovar.ptr, m, dense.decay_constant(500.0), S.ptr, mp))
+        info = C.c_int(-1)
+        ctx.check(lib.oisat_potrf(ctx.h, S1.ptr, m, mp, C.byref(info)))
+        refs.append(ctx.download(S1.ptr, (mp, mp), np.float32))
+        mats.append((S2, ctx.alloc(mp * 128 * 4), m, mp))
+    n = len(mats)
+    Sp = (C.c_void_p * n)(*[a[0].ptr for a in mats])
+    Tp = (C.c_void_p * n)(*[a[1].ptr for a in mats])
+    mm = (C.c_int64 * n)(*[a[2] for a in mats])
+    ld = (C.c_int64 * n)(*[a[3] for a in mats])
+    bid = C.c_int(-1)
+    ctx.check(lib.oisat_batch_create(ctx.h, n, Sp, mm, ld, Tp, C.byref(bid)))
+    info2 = (C.c_int * 2)(-1, -1)
+    ctx.check(lib.oisat_batch_potrf(ctx.h, bid.value, info2))
+    assert list(info2) == [0, -1]
+    for (S2, T, m, mp), ref in zip(mats, refs):
+        got = ctx.download(S2.ptr, (mp, mp), np.float32)
+        if m == max(sizes):
+            np.testing.assert_array_equal(np.tril(got), np.tril(ref))
+        else:
+            assert np.abs(np.tril(got) - np.tril(ref)).max() <= 4e-6 * np.abs(np.tril(ref)).max()
+        # the adopted factor solves: z = S^-1 rhs through oisat_potrs on this handle
+        ctx.check(lib.oisat_factor_adopt(ctx.h, S2.ptr, m, mp, T.ptr))
+        rhs = np.random.default_rng(m).normal(size=m)
+        zb = ctx.upload(rhs)
+        ctx.check(lib.oisat_potrs(ctx.h, S2.ptr, m, mp, zb.ptr))
+        z = ctx.download(zb.ptr, (m,), np.float64)
+        Lh = np.tril(ref[:m, :m]).astype(np.float64)
+        zr = np.linalg.solve(Lh @ Lh.T, rhs)
+        assert np.linalg.norm(z - zr) <= 1e-3 * np.linalg.norm(zr)
+    ctx.check(lib.oisat_batch_destroy(ctx.h, bid.value))
+    # one bad member: reported with the caller's index
+    good = (4.0 * np.eye(384) + 0.5).astype(np.float32)
+    bad = np.eye(256, dtype=np.float32)
+    bad[200, 200] = -1.0
+    Gb, Bb = ctx.upload(good), ctx.upload(bad)
+    Tg, Tb = ctx.alloc(384 * 128 * 4), ctx.alloc(256 * 128 * 4)
+    Sp = (C.c_void_p * 2)(Gb.ptr, Bb.ptr)
+    Tp = (C.c_void_p * 2)(Tg.ptr, Tb.ptr)
+    mm = (C.c_int64 * 2)(384, 256)
+    ld = (C.c_int64 * 2)(384, 256)
+    ctx.check(lib.oisat_batch_create(ctx.h, 2, Sp, mm, ld, Tp, C.byref(bid)))
+    with pytest.raises(_hip.OisatError, match="matrix 1 not positive definite at column 201"):
+        ctx.check(lib.oisat_batch_potrf(ctx.h, bid.value, info2))
+    assert list(info2) == [201, 1]
+    assert ctx.solve_status() == (0, 0, 0)                    # reported through the return code, not twice
+    Lg = np.tril(ctx.download(Gb.ptr, (384, 384), np.float32)).astype(np.float64)
+    assert np.abs(Lg @ Lg.T - good).max() <= 1e-5             # the good member is still factored
+    ctx.check(lib.oisat_batch_destroy(ctx.h, bid.value))
+
+
+def test_batched_and_lane_serial_tiled_analyses_agree(ctx):
+    """TiledAnalysis(batched=True) -- build on the lanes, lock-step factorization, solve on the lanes -- gives the fields of
+    TiledAnalysis(batched=False), where every lane runs its tiles' pipelines back to back, to refinement accuracy (the
+    fp32 factors differ in their last bits, the float64-residual refinement removes most of that)."""
+    p = syn.point_obs_case(90, 180, 6000, 5151)
+    L = 350.0
+    res = []
+    for batched in (True, False):
+        ta = dense.TiledAnalysis(p.lat, p.lon, tile_deg=30.0, halo_km=3 * L, dtype=np.float32, streams=5, batched=batched)
+        ta.load(p.Xa, p.Sa, p.obs_lat, p.obs_lon, p.obs_y, p.obs_var)
+        ta.run(L, refine=2, check_pd=True)
+        ta.run(L, refine=2)
+        res.append(ta.download())
+        ta.close()
+    scale = np.abs(p.Xa).max()
+    assert np.abs(res[0][0] - res[1][0]).max() <= 2e-6 * scale
+    assert np.abs(res[0][1] - res[1][1]).max() <= 2e-6 * scale
+    assert np.abs(res[0][1]).max() > 1e-2 * scale
