@@ -177,10 +177,21 @@ def tier_a_leg(ctx, ny, nx, nobs, sync):
                                           "8 B/cell read once = %.1f GB/s" % (8.0 * n / (curve_ms * 1e-3) / 1e9)}}
 
 
-def _hbm(bytes_, ms):
+TIER_A_PMC = os.path.join(ROOT, "profiles", "r02_a_tier_a_pmc_traffic.json")
+
+
+def _hbm(bytes_, ms, pmc_kernel=None):
+    """HBM roofline entry of one kernel launch; `traffic` = bytes the PMC passes of this same leg counted for that kernel
+    (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, offline: profiles/r02_a_tier_a_pmc_traffic.json), per launch."""
     gbs = bytes_ / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-            "algorithmic_bytes": int(bytes_), "kernel_ms": ms}
+    out = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+           "algorithmic_bytes": int(bytes_), "kernel_ms": ms, "traffic": None}
+    if pmc_kernel and os.path.exists(TIER_A_PMC):
+        rec = json.load(open(TIER_A_PMC))["bytes_per_dispatch"].get(pmc_kernel)
+        if rec:
+            out["traffic"] = rec["total"]
+            out["traffic_source"] = "profiles/r02_a_tier_a_pmc_traffic.json: " + pmc_kernel
+    return out
 
 
 def _prof_mean(ctx, fn, reps):
@@ -217,8 +228,9 @@ def tier_a_kernels_leg(ctx, sync):
         res = ctx.alloc(n * item)
         t = _prof_mean(ctx, lambda: (ctx.check(ctx.lib.oisat_nanmean_stack(ctx.h, code, stack.ptr, k, n, 1, res.ptr)),
                                      ctx.check(ctx.lib.oisat_error_average(ctx.h, code, stack.ptr, k, n, 1, res.ptr))), 10)
-        out[f"nanmean_stack_{tag}"] = _hbm((k + 1) * n * item, t["nanmean_stack"])
-        out[f"error_average_{tag}"] = _hbm((k + 1) * n * item, t["error_average"])
+        cname = "float" if item == 4 else "double"
+        out[f"nanmean_stack_{tag}"] = _hbm((k + 1) * n * item, t["nanmean_stack"], f"stack_reduce_kernel<{cname}, false>")
+        out[f"error_average_{tag}"] = _hbm((k + 1) * n * item, t["error_average"], f"stack_reduce_kernel<{cname}, true>")
         stack.free()
         # element-wise OI, analysis kernel + the whole fused call
         c = syn.diag_case(ny, nx, 100000, 3001)
@@ -226,7 +238,7 @@ def tier_a_kernels_leg(ctx, sync):
         d.load(c.Xa, c.Y, c.Sa, c.So)
         t = _prof_mean(ctx, lambda: d.run_fused(True), 10)
         el = time_steps(lambda: d.run_fused(True), 30, 3, sync)
-        out[f"oi_apply_{tag}"] = _hbm(8 * n * item, t["oi_apply"])
+        out[f"oi_apply_{tag}"] = _hbm(8 * n * item, t["oi_apply"], f"oi_apply_kernel<{cname}>")
         out[f"oi_fused_{tag}"] = {"ms_per_call": 1e3 * el / 30, "value": n * 30 / el, "unit": "grid-cells/s",
                                   "oi_curve_ms": t["oi_curve"], "oi_curve_read_GBs": 2 * n * item / (t["oi_curve"] * 1e-3) / 1e9}
         # _upscaler: 10 x 10 box filter evaluated at the fine nodes the 72 x 144 model cells pick, 8 stacked fields
@@ -236,7 +248,8 @@ def tier_a_kernels_leg(ctx, sync):
         nf = 8
         fine = ctx.upload(rng.uniform(0.0, 1.0, size=(nf, n)), dtype=dt)
         t = _prof_mean(ctx, lambda: plan.run(fine, nf, dt, False), 10)
-        out[f"boxfilter_pick_{tag}"] = _hbm(nf * plan.T * (plan.kx * plan.ky + 1) * item, t["boxfilter_pick"])
+        out[f"boxfilter_pick_{tag}"] = _hbm(nf * plan.T * (plan.kx * plan.ky + 1) * item, t["boxfilter_pick"],
+                                            f"boxfilter_pick_kernel<{cname}, 64>")
         out[f"boxfilter_pick_{tag}"]["window"] = [plan.ky, plan.kx]
         out[f"boxfilter_pick_{tag}"]["model_cells"] = plan.T
         fine.free()
@@ -660,8 +673,6 @@ def main():
             out["tier_a_kernels"] = tier_a_kernels_leg(ctx, sync)
             out["pcie_inclusive"] = pcie_leg(sync)
             out["regrid"] = regrid_leg(ctx, sync)
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload)
     if not args.no_config4:
         del gather
         if world > 1:
@@ -669,6 +680,8 @@ def main():
         c4 = config4_leg(ctx, args, world, rank, local, lat2, lon2, sync, barrier)
         if rank == 0:
             out["config4_strong"] = c4
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # last: its BLAS threads keep spinning for a while
+        out["cpu_baseline"] = cpu_baseline(args.workload)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

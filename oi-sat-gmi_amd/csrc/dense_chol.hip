@@ -81,23 +81,37 @@ __device__ __forceinline__ bool batch_operands(const BatchArgs& ba, int which, i
     return true;
 }
 
-// ---- gemm_nt ---------------------------------------------------------------------------------
-// mode 0: C -= A*B^T      mode 1: C = A*B^T (C may alias A when N == K == 128: TRSM-as-GEMM)
-// lower != 0: the C region is anchored on the diagonal; tiles strictly above it are skipped.
+// Virtual id -> work item for launches whose ids are NOT all equally loaded (batched launches: the ids past a smaller
+// matrix's tile count are empty).  Workgroups go to the 8 XCDs round-robin in dispatch order; giving each XCD one
+// contiguous eighth of the whole range (as gemm_nt_big does for a single matrix) would hand some XCDs mostly empty ids.
+// Instead every run of 512 ids is dealt out in 64-id chunks: id 512g + 8s + x (XCD x, its s-th workgroup of the run)
+// -> 512g + 64x + s, so an XCD still works on 64 consecutive items (an 8x8 patch of tiles in row-band order) and all
+// XCDs sweep the range together.  The ragged tail of the range keeps its ids.
+__device__ __forceinline__ int64_t xcd_chunk_remap(int64_t v, int64_t total) {
+    const int64_t g = v >> 9;
+    if (((g + 1) << 9) > total) return v;
+    const int64_t x = v & 7, sidx = (v >> 3) & 63;
+    return (g << 9) + (x << 6) + sidx;
+}
+
+// ---- gemm_nt_big: one tile per workgroup, for K >= 2048 --------------------------------------------------------------
+// The kernel the headline factorization spends 95 % of its time in (round 1's gemm_nt, unchanged): with 64+ K-steps per
+// tile the 22 us of per-tile overhead are < 10 %, and this instruction schedule of the K-loop sustains 140 TFLOP/s at
+// 8192^3 where the pipelined-across-tiles kernel below, with 64 more live registers for the prefetched C tile, reaches
+// 135 (measured: K = 1024: 913 vs 870 us for 3240 tiles, K = 2048: 1683 vs 1684, K = 5120: 4054 vs 4250).
 template <bool BATCH>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(float* C, int64_t ldc, const float* A,
+__global__ __launch_bounds__(256, 2) void gemm_nt_big_kernel(float* C, int64_t ldc, const float* A,
                                                           int64_t lda, const float* __restrict__ B, int64_t ldb, int ntm,
                                                           int ntn, int K, int mode, int lower, int ntiles_total, BatchArgs ba) {
     __shared__ __attribute__((aligned(16))) float lds[2][2][NB * BK];        // [buf][A|B][row*32 + 4*(chunk ^ (row&7))] = 65,536 B
     int wg;
     if (BATCH) {
         const float* Bb = nullptr;
-        // Workgroups go to the 8 XCDs round-robin in dispatch order (x fastest, then y).  Same bijective remap as below
-        // over the whole 2-D grid: each XCD gets a contiguous run of (matrix, tile) pairs, i.e. neighbouring tiles of
-        // the same matrix share its L2.
+        // Workgroups go to the 8 XCDs round-robin in dispatch order (x fastest, then y): chunked remap over the 2-D grid
+        // (xcd_chunk_remap), so that neighbouring tiles of the same matrix share an L2 and no XCD is left with the
+        // empty ids of the smaller matrices.
         const int64_t total = (int64_t)gridDim.x * gridDim.y, orig = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
-        const int64_t xcd = orig & 7, q = total >> 3, r = total & 7;
-        const int64_t lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+        const int64_t lin = xcd_chunk_remap(orig, total);
         const int which = (int)(lin / gridDim.x);
         if (!batch_operands(ba, which, NB, C, ldc, A, lda, Bb, ldb, ntm, ntn)) return;
         B = Bb;
@@ -223,6 +237,208 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(float* C, int64_t ldc, 
     OISAT_EPI(acc01, 0, 1)
     OISAT_EPI(acc10, 1, 0)
     OISAT_EPI(acc11, 1, 1)
+}
+#undef OISAT_DMA
+#undef OISAT_FRAG
+#undef OISAT_MFMA4
+#undef OISAT_MFMA16
+#undef OISAT_EPI
+
+// ---- gemm_nt ---------------------------------------------------------------------------------
+// mode 0: C -= A*B^T      mode 1: C = A*B^T (C may alias A when N == K == 128: TRSM-as-GEMM)
+// lower != 0: the C region is anchored on the diagonal; tiles strictly above it are skipped.
+//
+// PERSISTENT workgroups: the grid is min(tiles, 2 per CU) and workgroup b walks the tiles b, b + G, b + 2G, ...  A
+// tile's fixed costs -- the first operand load in front of an idle MFMA pipe, the read-modify-write of C behind it --
+// measured 22 us per tile (the time of six K-steps; 37 us per tile at K = 128, 81 us at K = 512 against 15 / 62 us of
+// MFMA work), which is what the tall-and-thin updates deep in the recursion and every update of a 4,000-18,000-
+// observation tile are made of.  Here the pipeline runs ACROSS tiles: the first K-step of the next tile is fetched (LDS-
+// DMA into the free buffer) during the last K-step of the current one, and the C tile is prefetched into registers at
+// the start of that last K-step, so the epilogue is 64 stores and the next tile's MFMAs start right behind it.
+// Bit-identical to the one-tile-per-workgroup form (same accumulation order, C - sum rounded once).
+template <bool BATCH>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(float* C0, int64_t ldc0, const float* A0, int64_t lda0,
+                                                          const float* __restrict__ B0, int64_t ldb0, int ntm0, int ntn0, int K,
+                                                          int mode, int lower, int ntiles_total, BatchArgs ba) {
+    __shared__ __attribute__((aligned(16))) float lds[2][2][NB * BK];        // [buf][A|B][row*32 + 4*(chunk ^ (row&7))] = 65,536 B
+    const int t = threadIdx.x;
+    const int lane = t & 63, wid = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = wid >> 1, wc = wid & 1;
+    // virtual tile ids: plain launch: the tiles of C;  batched launch: (ntm0 = tiles of the largest matrix) x (ntn0 = matrices)
+    const int64_t VT = BATCH ? (int64_t)ntm0 * ntn0 : (int64_t)ntiles_total;
+    const int64_t G = gridDim.x;                            // a multiple of 8 whenever a workgroup gets more than one tile
+    // LDS-DMA (global_load_lds_dwordx4): wave `wid` brings rows wid*32 + 8i .. +7 (i = 0..3) of each operand, one KiB
+    // per instruction, straight into LDS -- no staging registers, no ds_write, and the wave only waits for its pieces
+    // right before the barrier.  A DMA instruction fills LDS linearly (lane l -> 16 bytes at 16 l), so the image cannot
+    // be padded; it is XOR-swizzled instead: lane l lands at physical chunk (l&7) of row (l>>3) and therefore fetches
+    // the LOGICAL chunk (l&7) ^ (row&7) of that row from global memory (still one 128-byte segment per row).
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const int rl = lane >> 3, lc = (lane & 7) ^ rl;
+    const int frow = lane & 31, fh = lane >> 5;
+
+    // virtual id -> tile.  Workgroups go to the 8 XCDs round-robin in dispatch order, and v = b + iG keeps b's XCD (G is
+    // a multiple of 512 / 8): xcd_chunk_remap hands each XCD (private 4 MiB L2) 64 consecutive ids at a time, which the
+    // row-band order below turns into 8x8 patches of tiles that share operand panels (in a batched launch: neighbouring
+    // tiles of the same matrix).
+    // Row-band order: bands of 8 tile rows, inside a band column by column; in `lower` mode only tiles with ti >= tj
+    // are enumerated (the last columns of a band are partial).  The band search is a short wave-uniform loop.
+    auto locate = [&](int64_t v, const float*& oAd, const float*& oBd, float*& oCg, int64_t& olda, int64_t& oldb,
+                      int64_t& oldc) -> int64_t {
+        for (; v < VT; v += G) {
+            const int64_t lin = xcd_chunk_remap(v, VT);
+            float* C = C0;
+            const float* A = A0;
+            const float* B = B0;
+            int64_t lda = lda0, ldb = ldb0, ldc = ldc0;
+            int ntm = ntm0, ntn = ntn0, wg = (int)lin;
+            if (BATCH) {
+                const int which = (int)(lin / ntm0);
+                wg = (int)(lin - (int64_t)which * ntm0);
+                if (!batch_operands(ba, which, NB, C, ldc, A, lda, B, ldb, ntm, ntn)) continue;
+            }
+            int ti = 0, tj = 0, rem = wg;
+            bool found = false;
+            for (int R0 = 0; R0 < ntm; R0 += 8) {
+                const int R1 = (R0 + 7 < ntm ? R0 + 7 : ntm - 1), nr = R1 - R0 + 1;
+                const int cmax = lower ? (R1 < ntn - 1 ? R1 : ntn - 1) : ntn - 1;       // last column of this band
+                const int cfull = lower ? (R0 < cmax ? R0 : cmax) : cmax;               // columns 0..cfull hold all nr rows
+                const int tri = cmax - cfull;                                           // partial columns cfull+1..cmax
+                const int count = nr * (cfull + 1) + tri * (R1 - cfull + 1) - tri * (tri + 1) / 2;   // + sum_{c} (R1 - c + 1)
+                if (rem < count) {
+                    if (rem < nr * (cfull + 1)) {
+                        tj = rem / nr;
+                        ti = R0 + rem - tj * nr;
+                    } else {
+                        rem -= nr * (cfull + 1);
+                        int c = cfull + 1;
+                        while (rem >= R1 - c + 1) { rem -= R1 - c + 1; ++c; }
+                        tj = c;
+                        ti = c + rem;
+                    }
+                    found = true;
+                    break;
+                }
+                rem -= count;
+            }
+            if (!found) continue;                           // batched: this matrix has fewer tiles than the largest one
+            oAd = A + ((int64_t)ti * NB + wid * 32 + rl) * lda + 4 * lc;
+            oBd = B + ((int64_t)tj * NB + wid * 32 + rl) * ldb + 4 * lc;
+            oCg = C + ((int64_t)ti * NB + wr * 64) * ldc + (int64_t)tj * NB + wc * 64;
+            olda = lda;
+            oldb = ldb;
+            oldc = ldc;
+            return v;
+        }
+        return -1;
+    };
+#define OISAT_DMA(buf, PA, PB, LA, LB, k0)                                                                         \
+    do {                                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                            \
+            __builtin_amdgcn_global_load_lds((gptr_t)((PA) + (int64_t)(8 * i) * (LA) + (k0)),                      \
+                                             (lptr_t)&lds[buf][0][(wid * 32 + 8 * i) * BK], 16, 0, 0);             \
+            __builtin_amdgcn_global_load_lds((gptr_t)((PB) + (int64_t)(8 * i) * (LB) + (k0)),                      \
+                                             (lptr_t)&lds[buf][1][(wid * 32 + 8 * i) * BK], 16, 0, 0);             \
+        }                                                                                                          \
+    } while (0)
+    const float *Ad = nullptr, *Bd = nullptr, *nAd = nullptr, *nBd = nullptr;
+    float *Cg = nullptr, *nCg = nullptr;
+    int64_t lda = 0, ldb = 0, ldc = 0, nlda = 0, nldb = 0, nldc = 0;
+    int64_t v = locate(blockIdx.x, Ad, Bd, Cg, lda, ldb, ldc);
+    if (v < 0) return;
+
+    const int nkt = K / BK;
+    OISAT_DMA(0, Ad, Bd, lda, ldb, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // a lane's fragment of K-group s is logical chunk 2s+fh of its row: physical chunk (2s+fh) ^ (row&7).  Any 8 consecutive
+    // rows hold one logical chunk in 8 different physical chunks = all 32 banks once: conflict-free ds_read_b128.
+    const int sw = frow & 7;
+    const int arow = (wr * 64 + frow) * BK, brow = (wc * 64 + frow) * BK;
+    // fragment registers, two sets: the operands of MFMA group s+1 are read from LDS while group s runs
+    float4 fa0, fa1, fb0, fb1, ga0, ga1, gb0, gb1;
+#define OISAT_FRAG(A0, A1, B0, B1, buf, s)                                                      \
+    do {                                                                                        \
+        A0 = *reinterpret_cast<const float4*>(&lds[buf][0][arow + 4 * ((2 * (s) + fh) ^ sw)]);            \
+        A1 = *reinterpret_cast<const float4*>(&lds[buf][0][arow + 32 * BK + 4 * ((2 * (s) + fh) ^ sw)]);  \
+        B0 = *reinterpret_cast<const float4*>(&lds[buf][1][brow + 4 * ((2 * (s) + fh) ^ sw)]);            \
+        B1 = *reinterpret_cast<const float4*>(&lds[buf][1][brow + 32 * BK + 4 * ((2 * (s) + fh) ^ sw)]);  \
+    } while (0)
+#define OISAT_MFMA4(A0, A1, B0, B1, c)                                                          \
+    acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.c, B0.c, acc00, 0, 0, 0);                   \
+    acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.c, B1.c, acc01, 0, 0, 0);                   \
+    acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.c, B0.c, acc10, 0, 0, 0);                   \
+    acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.c, B1.c, acc11, 0, 0, 0);
+#define OISAT_MFMA16(A0, A1, B0, B1)                                                            \
+    OISAT_MFMA4(A0, A1, B0, B1, x) OISAT_MFMA4(A0, A1, B0, B1, y) OISAT_MFMA4(A0, A1, B0, B1, z) OISAT_MFMA4(A0, A1, B0, B1, w)
+    // C/D layout: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).  The 64 elements a lane owns are addressed through
+    // a buffer descriptor on the wave's 64x64 quadrant: ONE per-lane offset register (row 4*fh, column frow) and a
+    // wave-uniform scalar offset per element -- 64 separate 64-bit addresses would not fit next to 64 prefetched values.
+#define OISAT_CRSRC()                                                                                   \
+    __builtin_amdgcn_make_buffer_rsrc((void*)Cg, (short)0, (int)(64 * ldc * 4), 0x00020000)
+#define OISAT_CSOFF(i, j, e) (int)((((i) * 32 + ((e) & 3) + 8 * ((e) >> 2)) * ldc + (j) * 32) * 4)
+#define OISAT_CPRE(DST, i, j)                                                                           \
+    _Pragma("unroll") for (int e = 0; e < 16; ++e)                                                      \
+        DST[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(crs, cvoff, OISAT_CSOFF(i, j, e), 0));
+#define OISAT_EPI(ACC, PRE, i, j)                                                                       \
+    _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                    \
+        const float o = (mode == 0) ? PRE[e] - ACC[e] : ACC[e];                                         \
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), crs, cvoff, OISAT_CSOFF(i, j, e), 0); \
+    }
+    int base = 0;                                           // LDS buffer that holds K-step 0 of the current tile
+    OISAT_FRAG(fa0, fa1, fb0, fb1, 0, 0);
+    while (true) {
+        const int64_t nv = locate(v + G, nAd, nBd, nCg, nlda, nldb, nldc);
+        const bool has_next = nv >= 0;
+        f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+        f32x16 c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0};
+        const __amdgpu_buffer_rsrc_t crs = OISAT_CRSRC();
+        const int cvoff = (int)(((4 * fh) * ldc + frow) * 4);
+        // steady state: the loop of the one-tile kernel, branch-free (one scheduling region)
+        for (int kt = 0; kt + 1 < nkt; ++kt) {
+            const int cur = (kt + base) & 1;
+            OISAT_DMA(cur ^ 1, Ad, Bd, lda, ldb, (kt + 1) * BK);   // the other buffer is free since the last barrier
+            OISAT_FRAG(ga0, ga1, gb0, gb1, cur, 1);
+            OISAT_MFMA16(fa0, fa1, fb0, fb1)                       // s = 0
+            OISAT_FRAG(fa0, fa1, fb0, fb1, cur, 2);
+            OISAT_MFMA16(ga0, ga1, gb0, gb1)                       // s = 1
+            OISAT_FRAG(ga0, ga1, gb0, gb1, cur, 3);
+            OISAT_MFMA16(fa0, fa1, fb0, fb1)                       // s = 2
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's DMA pieces of K-step kt+1 have landed ...
+            __syncthreads();                                        // ... and so have everyone else's; every read of K-step kt has been issued
+            OISAT_FRAG(fa0, fa1, fb0, fb1, cur ^ 1, 0);             // first operands of the next K-step, behind the last MFMA group
+            OISAT_MFMA16(ga0, ga1, gb0, gb1)                       // s = 3
+        }
+        {   // last K-step of this tile: K-step 0 of the NEXT tile goes to the free buffer, the C tile to registers
+            const int cur = (nkt - 1 + base) & 1;
+            if (has_next) OISAT_DMA(cur ^ 1, nAd, nBd, nlda, nldb, 0);
+            if (mode == 0) {
+                OISAT_CPRE(c00, 0, 0)
+                OISAT_CPRE(c01, 0, 1)
+                OISAT_CPRE(c10, 1, 0)
+                OISAT_CPRE(c11, 1, 1)
+            }
+            OISAT_FRAG(ga0, ga1, gb0, gb1, cur, 1);
+            OISAT_MFMA16(fa0, fa1, fb0, fb1)                       // s = 0
+            OISAT_FRAG(fa0, fa1, fb0, fb1, cur, 2);
+            OISAT_MFMA16(ga0, ga1, gb0, gb1)                       // s = 1
+            OISAT_FRAG(ga0, ga1, gb0, gb1, cur, 3);
+            OISAT_MFMA16(fa0, fa1, fb0, fb1)                       // s = 2
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (has_next) OISAT_FRAG(fa0, fa1, fb0, fb1, cur ^ 1, 0);
+            OISAT_MFMA16(ga0, ga1, gb0, gb1)                       // s = 3
+        }
+        OISAT_EPI(acc00, c00, 0, 0)
+        OISAT_EPI(acc01, c01, 0, 1)
+        OISAT_EPI(acc10, c10, 1, 0)
+        OISAT_EPI(acc11, c11, 1, 1)
+        if (!has_next) break;
+        base = (base + nkt) & 1;
+        v = nv;
+        Ad = nAd; Bd = nBd; Cg = nCg;
+        lda = nlda; ldb = nldb; ldc = nldc;
+    }
 }
 
 // ---- gemm_nt for launches that cannot fill the chip with 128x128 tiles ------------------------------
@@ -876,6 +1092,16 @@ __global__ __launch_bounds__(256) void gain_diag_kernel(const double* __restrict
     ak[a0 + r] = 1.0 - ovar[a0 + r] * ss[r];         // diag(K H) at the observation: 1 - R_aa (S^-1)_aa
 }
 
+static const int kBigK = getenv("OISAT_GEMM_BIG_K") ? atoi(getenv("OISAT_GEMM_BIG_K")) : 2048;   // K from which gemm_nt_big_kernel is used
+
+// grid of the persistent gemm_nt_kernel: every tile its own workgroup while they all fit (2 per CU), else 2 per CU
+// (a multiple of 8, so that workgroup b keeps its XCD for all of its tiles)
+static inline unsigned persistent_grid(const oisat_ctx* h, int64_t virtual_tiles) {
+    static const int per_cu = getenv("OISAT_GEMM_WG_PER_CU") ? atoi(getenv("OISAT_GEMM_WG_PER_CU")) : 2;
+    const int64_t slots = ((int64_t)(h->cu_count > 0 ? h->cu_count : 256) * per_cu) / 8 * 8;
+    return (unsigned)(virtual_tiles <= slots || per_cu <= 0 ? virtual_tiles : slots);
+}
+
 int launch_gemm(oisat_ctx* h, const char* name, float* C, int64_t ldc, const float* A, int64_t lda, const float* B, int64_t ldb,
                 int64_t M, int64_t N, int K, int mode, int lower) {
     const int ntm = (int)(M / NB), ntn = (int)(N / NB);
@@ -900,8 +1126,13 @@ int launch_gemm(oisat_ctx* h, const char* name, float* C, int64_t ldc, const flo
         oisat_set_error("gemm grid too large");
         return OISAT_EINVAL;
     }
-    OISAT_LAUNCH(h, name, gemm_nt_kernel<false>, dim3((unsigned)ntiles), dim3(256), 0, C, ldc, A, lda, B, ldb, ntm, ntn, K, mode, lower,
-                 (int)ntiles, BatchArgs{});
+    if (K >= kBigK) {
+        OISAT_LAUNCH(h, name, gemm_nt_big_kernel<false>, dim3((unsigned)ntiles), dim3(256), 0, C, ldc, A, lda, B, ldb, ntm, ntn, K, mode,
+                     lower, (int)ntiles, BatchArgs{});
+        return OISAT_OK;
+    }
+    OISAT_LAUNCH(h, name, gemm_nt_kernel<false>, dim3(persistent_grid(h, ntiles)), dim3(256), 0, C, ldc, A, lda, B, ldb, ntm, ntn, K, mode,
+                 lower, (int)ntiles, BatchArgs{});
     return OISAT_OK;
 }
 
@@ -932,8 +1163,8 @@ int launch_gemm_batched(oisat_ctx* h, const char* name, const ChBatch& bt, Batch
             OISAT_LAUNCH(h, name, gemm_nt_rows64_kernel<true>, dim3((unsigned)(rows * 2), (unsigned)cnt), dim3(256), 0, (float*)nullptr,
                          (int64_t)0, (const float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0, K, mode, ba);
         } else {
-            OISAT_LAUNCH(h, name, gemm_nt_kernel<true>, dim3((unsigned)rows, (unsigned)cnt), dim3(256), 0, (float*)nullptr, (int64_t)0,
-                         (const float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0, 0, 0, K, mode, 0, 0, ba);
+            OISAT_LAUNCH(h, name, gemm_nt_kernel<true>, dim3(persistent_grid(h, rows * cnt)), dim3(256), 0, (float*)nullptr, (int64_t)0,
+                         (const float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0, (int)rows, cnt, K, mode, 0, 0, ba);
         }
         return OISAT_OK;
     }
@@ -942,9 +1173,12 @@ int launch_gemm_batched(oisat_ctx* h, const char* name, const ChBatch& bt, Batch
         const int64_t st = lower ? tiles_lower(rows * 2, cols * 2) : rows * cols * 4;
         OISAT_LAUNCH(h, name, gemm_nt_small_kernel<true>, dim3((unsigned)st, (unsigned)cnt), dim3(256), 0, (float*)nullptr, (int64_t)0,
                      (const float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0, 0, 0, K, mode, lower, ba);
-    } else {
-        OISAT_LAUNCH(h, name, gemm_nt_kernel<true>, dim3((unsigned)mx, (unsigned)cnt), dim3(256), 0, (float*)nullptr, (int64_t)0,
+    } else if (K >= kBigK) {
+        OISAT_LAUNCH(h, name, gemm_nt_big_kernel<true>, dim3((unsigned)mx, (unsigned)cnt), dim3(256), 0, (float*)nullptr, (int64_t)0,
                      (const float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0, 0, 0, K, mode, lower, 0, ba);
+    } else {
+        OISAT_LAUNCH(h, name, gemm_nt_kernel<true>, dim3(persistent_grid(h, mx * cnt)), dim3(256), 0, (float*)nullptr, (int64_t)0,
+                     (const float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0, (int)mx, cnt, K, mode, lower, 0, ba);
     }
     return OISAT_OK;
 }
