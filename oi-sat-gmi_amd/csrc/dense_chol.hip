@@ -860,6 +860,216 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(float* __restrict__ S, 
     }
 }
 
+// ---- diagonal block, TWO LDS images (the default): Cholesky + inverse of one 128x128 block, one workgroup ------------
+// 33 us per block against 43 us for the one-image kernel above (its masked operand reads, the register-held T21 tiles
+// and the transposed store of T cost 10 us), at 137 KB of LDS: the workgroup needs a CU to itself.  That is what it
+// gets in the recursive single-matrix schedule and in a batched (lock-step) factorization -- nothing else runs on the
+// stream's critical path -- so both use this kernel; lane-concurrent analyses (TiledAnalysis(batched=False), where a
+// diagonal block of one tile must squeeze in next to the GEMMs of another) select the 67 KB kernel (oisat_diag_lds).
+// Right-looking at 16-column granularity, 4 waves.  Per block column J:
+//   (1) wave 0 factors the 16x16 diagonal block in registers (lane = row, columns in VGPRs, pivots
+//       broadcast with v_readlane) and inverts it the same way;
+//   (2) panel below:   P_I  = A[I,J] * Dinv_J^T          (v_mfma_f32_16x16x4_f32, 4 per 16x16 block)
+//   (3) trailing:      A[I,K] -= P_I * P_K^T,  J < K <= I
+// then T = L^-1 by doubling (16 -> 32 -> 64 -> 128):  T21 = -T22 * (L21 * T11), both products on
+// MFMA; the intermediate L21*T11 is parked in the unused upper triangle of the L image.
+// LDS: a[128][130] (L), t[128][130] (T), dinv[8][16][17].  Row stride 130 = 2 mod 32 keeps the
+// (row = lane&15, k = lane>>4) MFMA operand reads conflict-free.
+constexpr int DINV_LD = 17;
+constexpr int DINV_SZ = 16 * DINV_LD;
+
+
+// Factor and invert in ONE sweep: column k of L is final after pivot step k, and that is exactly when the forward
+// substitution for X = L^-1 (lane = column r of X) needs it, so each broadcast L[c][k] = readlane(d[k], c) feeds both
+// the trailing update of the factor and the running sums of the inverse.  Half the serial broadcasts of doing the
+// two one after the other.
+__device__ __forceinline__ void diag16_factor_invert2(float* a, int j0, float* dinvJ, int* info, int col0, int lane) {
+    const int r = lane & 15;
+    float d[16], x[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        d[c] = a[(j0 + r) * LDA + j0 + c];
+        x[c] = (c == r) ? 1.f : 0.f;                       // running delta_{c,r} - sum_{k<c} L[c][k] X[k][r]
+    }
+    int bad = 0;                                           // first non-positive / NaN pivot (wave-uniform), reported once below
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        float piv = rdlane(d[k], k);
+        const bool neg = !(piv > 0.f);
+        bad = (neg && bad == 0) ? k + 1 : bad;
+        piv = neg ? 1.f : piv;
+        float ri = __builtin_amdgcn_rsqf(piv);
+        ri = ri * (1.5f - 0.5f * piv * ri * ri);          // one Newton step: ~0.5 ulp
+        d[k] = (r == k) ? piv * ri : d[k] * ri;
+        x[k] = (k >= r) ? x[k] * ri : 0.f;
+#pragma unroll
+        for (int c = k + 1; c < 16; ++c) {
+            const float l = rdlane(d[k], c);              // L[c][k]
+            d[c] -= d[k] * l;
+            x[c] -= l * x[k];
+        }
+    }
+    if (bad && lane == 0) {               // info[0]: this factorization; info[1], info[2]: sticky (first column, count)
+        atomicCAS(info, 0, col0 + bad);
+        atomicCAS(info + 1, 0, col0 + bad);
+        atomicAdd(info + 2, 1);
+        atomicCAS(info + 3, 0, (int)blockIdx.x + 1);   // batched factorization: which matrix of the table (1-based)
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+        if (lane < 16) a[(j0 + r) * LDA + j0 + c] = (c <= r) ? d[c] : 0.f;
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr)
+        if (lane < 16) dinvJ[rr * DINV_LD + r] = x[rr];
+}
+
+__global__ __launch_bounds__(256) void potrf_diag2_kernel(float* __restrict__ S, int64_t ld, int64_t k0, float* __restrict__ tinv,
+                                                          int* __restrict__ info, int block_index, const BatchMat* __restrict__ mats) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    if (mats) {                            // batched: workgroup = matrix blockIdx.x of the table (largest first)
+        const BatchMat bm = mats[blockIdx.x];
+        if (block_index >= bm.mpb) return;
+        S = bm.S;
+        ld = bm.ld;
+        tinv = bm.tinv;
+    }
+    float* a = sm;                         // [128][LDA]
+    float* t = sm + NB * LDA;              // [128][LDA]
+    float* dinv = t + NB * LDA;            // [8][16][17]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lr = lane & 15, lg = lane >> 4;
+    float* Sb = S + k0 * ld + k0;
+    {   // 16 independent 16-byte loads per thread, issued together (row = (tid>>5)+8p, 4 columns at (tid&31)*4).
+        // Row stride 130 floats keeps (r, c) with c % 4 == 0 8-byte aligned: two ds_write_b64 per quad.
+        // (t needs no clearing: every element of it that is read later has been written by then.)
+        float4 v[16];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) v[p] = *reinterpret_cast<const float4*>(Sb + (int64_t)((tid >> 5) + 8 * p) * ld + (tid & 31) * 4);
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const int r = (tid >> 5) + 8 * p, c = (tid & 31) * 4;
+            float2* q = reinterpret_cast<float2*>(a + r * LDA + c);
+            q[0] = make_float2((c + 0 <= r) ? v[p].x : 0.f, (c + 1 <= r) ? v[p].y : 0.f);
+            q[1] = make_float2((c + 2 <= r) ? v[p].z : 0.f, (c + 3 <= r) ? v[p].w : 0.f);
+        }
+    }
+    __syncthreads();
+    // Look-ahead: while waves 1-3 apply the trailing update of block column J, wave 0 updates only the next
+    // diagonal block and immediately factors/inverts it, so the serial 16x16 factorizations (the longest
+    // single-wave stretch) hide behind the MFMA updates instead of adding to them.
+    if (w == 0) diag16_factor_invert2(a, 0, dinv, info, (int)k0, lane);
+    __syncthreads();
+    for (int J = 0; J < 8; ++J) {
+        const int j0 = 16 * J;
+        const float* dJ = dinv + J * DINV_SZ;
+        for (int I = J + 1 + w; I < 8; I += 4) {          // panel: P_I = A[I,J] * Dinv^T
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float av = a[(16 * I + lr) * LDA + j0 + 4 * s + lg];
+                const float bv = dJ[lr * DINV_LD + 4 * s + lg];               // B[k][j] = Dinv[j][k]
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[(16 * I + 4 * lg + e) * LDA + j0 + lr] = acc[e];
+        }
+        __syncthreads();
+        if (J == 7) break;
+        const int n = 7 - J, np = n * (n + 1) / 2;        // trailing pairs (I >= K > J); pair 0 = (J+1, J+1)
+        const int pfirst = (w == 0) ? 0 : w, pstep = (w == 0) ? np : 3;          // wave 0: pair 0 only
+        for (int p = pfirst; p < np; p += pstep) {
+            int kk = 0, rem = p;
+            while (rem >= n - kk) { rem -= n - kk; ++kk; }
+            const int K = J + 1 + kk, I = K + rem;
+            f32x4 acc;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = a[(16 * I + 4 * lg + e) * LDA + 16 * K + lr];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float av = -a[(16 * I + lr) * LDA + j0 + 4 * s + lg];
+                const float bv = a[(16 * K + lr) * LDA + j0 + 4 * s + lg];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[(16 * I + 4 * lg + e) * LDA + 16 * K + lr] = acc[e];
+        }
+        if (w == 0) diag16_factor_invert2(a, j0 + 16, dinv + (J + 1) * DINV_SZ, info, (int)(k0 + j0 + 16), lane);
+        __syncthreads();
+    }
+    // ---- T = L^-1 -----------------------------------------------------------------------------
+    for (int idx = tid; idx < 8 * 256; idx += 256) {       // diagonal 16-blocks of T
+        const int J = idx >> 8, rr = (idx >> 4) & 15, cc = idx & 15;
+        t[(16 * J + rr) * LDA + 16 * J + cc] = dinv[J * DINV_SZ + rr * DINV_LD + cc];
+    }
+    __syncthreads();
+    for (int hb = 1; hb <= 4; hb *= 2) {                   // half size in 16-blocks
+        const int h = 16 * hb, npairs = 8 / (2 * hb), nout = npairs * hb * hb;
+        // phase A: X = L21 * T11  -> upper mirror of a
+        for (int o = w; o < nout; o += 4) {
+            const int pr = o / (hb * hb), bi = (o / hb) % hb, bj = o % hb;
+            const int c0 = pr * 2 * h;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int kb = bj; kb < hb; ++kb) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float av = a[(c0 + h + 16 * bi + lr) * LDA + c0 + 16 * kb + 4 * s + lg];
+                    const float bv = t[(c0 + 16 * kb + 4 * s + lg) * LDA + c0 + 16 * bj + lr];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[(c0 + 16 * bi + 4 * lg + e) * LDA + c0 + h + 16 * bj + lr] = acc[e];
+        }
+        __syncthreads();
+        // phase B: T21 = -T22 * X
+        for (int o = w; o < nout; o += 4) {
+            const int pr = o / (hb * hb), bi = (o / hb) % hb, bj = o % hb;
+            const int c0 = pr * 2 * h;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int kb = 0; kb <= bi; ++kb) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float av = -t[(c0 + h + 16 * bi + lr) * LDA + c0 + h + 16 * kb + 4 * s + lg];
+                    const float bv = a[(c0 + 16 * kb + 4 * s + lg) * LDA + c0 + h + 16 * bj + lr];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[(c0 + h + 16 * bi + 4 * lg + e) * LDA + c0 + 16 * bj + lr] = acc[e];
+        }
+        __syncthreads();
+    }
+    float* Tg = tinv + (int64_t)block_index * NB * NB;
+#pragma unroll
+    for (int hp = 0; hp < 2; ++hp) {       // LDS reads of 8 rows first (ds_read_b64), then their stores
+        float2 ql[8][2], zl[8][2];
+#pragma unroll
+        for (int pp = 0; pp < 8; ++pp) {
+            const int r = (tid >> 5) + 8 * (hp * 8 + pp), c = (tid & 31) * 4;
+            const float2* q = reinterpret_cast<const float2*>(a + r * LDA + c);
+            const float2* z = reinterpret_cast<const float2*>(t + r * LDA + c);
+            ql[pp][0] = q[0]; ql[pp][1] = q[1];
+            zl[pp][0] = z[0]; zl[pp][1] = z[1];
+        }
+#pragma unroll
+        for (int pp = 0; pp < 8; ++pp) {
+            const int r = (tid >> 5) + 8 * (hp * 8 + pp), c = (tid & 31) * 4;
+            float* g = Sb + (int64_t)r * ld + c;
+            if (c + 3 <= r) *reinterpret_cast<float4*>(g) = make_float4(ql[pp][0].x, ql[pp][0].y, ql[pp][1].x, ql[pp][1].y);
+            else {
+                if (c + 0 <= r) g[0] = ql[pp][0].x;
+                if (c + 1 <= r) g[1] = ql[pp][0].y;
+                if (c + 2 <= r) g[2] = ql[pp][1].x;
+            }
+            // T above the diagonal was never written in LDS: select, do not multiply
+            *reinterpret_cast<float4*>(Tg + r * NB + c) = make_float4(c + 0 <= r ? zl[pp][0].x : 0.f, c + 1 <= r ? zl[pp][0].y : 0.f,
+                                                                       c + 2 <= r ? zl[pp][1].x : 0.f, c + 3 <= r ? zl[pp][1].y : 0.f);
+        }
+    }
+}
+
+constexpr size_t kDiag2Shm = sizeof(float) * (2 * NB * LDA + 8 * DINV_SZ);
+
 // identity padding of rows m..mp (columns 0..mp)
 __global__ __launch_bounds__(256) void pad_identity_kernel(float* __restrict__ S, int64_t ld, int64_t m, int64_t mp) {
     const int64_t total = (mp - m) * mp;
@@ -1191,8 +1401,13 @@ int potrf_rec_batched(oisat_ctx* h, const ChBatch& bt, int b0, int b1, int* info
             ++cnt;
         }
         if (cnt == 0) return OISAT_OK;
-        OISAT_LAUNCH(h, "potrf_diag", potrf_diag_kernel, dim3((unsigned)cnt), dim3(256), kDiagShm, (float*)nullptr, (int64_t)0,
-                     (int64_t)b0 * NB, (float*)nullptr, info_dev, b0, (const BatchMat*)bt.table_dev);
+        if (h->diag_small_lds) {
+            OISAT_LAUNCH(h, "potrf_diag", potrf_diag_kernel, dim3((unsigned)cnt), dim3(256), kDiagShm, (float*)nullptr, (int64_t)0,
+                         (int64_t)b0 * NB, (float*)nullptr, info_dev, b0, (const BatchMat*)bt.table_dev);
+        } else {
+            OISAT_LAUNCH(h, "potrf_diag", potrf_diag2_kernel, dim3((unsigned)cnt), dim3(256), kDiag2Shm, (float*)nullptr, (int64_t)0,
+                         (int64_t)b0 * NB, (float*)nullptr, info_dev, b0, (const BatchMat*)bt.table_dev);
+        }
         return launch_gemm_batched(h, "trsm_gemm", bt, BatchArgs{bt.table_dev, 1, b0, 0, 0}, NB, 1, 0);
     }
     const int mid = b0 + (b1 - b0 + 1) / 2;
@@ -1218,9 +1433,13 @@ __global__ __launch_bounds__(256) void pad_identity_batched_kernel(const BatchMa
 int potrf_rec(oisat_ctx* h, float* S, int64_t ld, int64_t mpb, int64_t b0, int64_t b1, float* tinv, int* info_dev) {
     if (b1 - b0 == 1) {
         const int64_t k0 = b0 * NB;
-        const size_t shm = kDiagShm;
-        OISAT_LAUNCH(h, "potrf_diag", potrf_diag_kernel, dim3(1), dim3(256), shm, S, ld, k0, tinv, info_dev, (int)b0,
-                     (const BatchMat*)nullptr);
+        if (h->diag_small_lds) {
+            OISAT_LAUNCH(h, "potrf_diag", potrf_diag_kernel, dim3(1), dim3(256), kDiagShm, S, ld, k0, tinv, info_dev, (int)b0,
+                         (const BatchMat*)nullptr);
+        } else {
+            OISAT_LAUNCH(h, "potrf_diag", potrf_diag2_kernel, dim3(1), dim3(256), kDiag2Shm, S, ld, k0, tinv, info_dev, (int)b0,
+                         (const BatchMat*)nullptr);
+        }
         const int64_t rows = (mpb - b0 - 1) * NB;
         if (rows > 0) {
             float* P = S + (k0 + NB) * ld + k0;                  // panel below the diagonal block
@@ -1380,6 +1599,8 @@ hipError_t dense_kernel_attributes() {
     static const hipError_t attr_rc = []() {
         hipError_t e = hipFuncSetAttribute((const void*)potrf_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)kDiagShm);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)potrf_diag2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDiag2Shm);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)trsv_pipe_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)(sizeof(float) * NB * TLD));
@@ -1710,5 +1931,11 @@ extern "C" int oisat_factor_adopt(oisat_ctx* h, const float* L, int64_t m, int64
     h->factor.mp = mp;
     h->factor.ld = ld;
     h->factor.tinv = tinv;
+    return OISAT_OK;
+}
+
+extern "C" int oisat_diag_lds(oisat_ctx* h, int small) {
+    ARG_CHECK(h != nullptr);
+    h->diag_small_lds = small != 0;
     return OISAT_OK;
 }
