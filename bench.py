@@ -642,12 +642,13 @@ def main():
                 bplans.append(q)
             bf = dense.BatchedFactor(ctx.device, bplans)
 
+            bpool = dense.LanePool.__new__(dense.LanePool)          # the eight handles above as a pool (no new streams)
+            bpool.ctx, bpool.lanes, bpool.factors, bpool._threads = ctx, blanes, [], None
+
             def months_batched():
                 for q in bplans:
                     q.run_build(L2)
-                bf.factor()
-                for q in bplans:
-                    q.run_solve(r2)
+                bf.run(bpool, [[q] for q in bplans], r2)
                 for l in blanes:
                     l.sync()
             months_batched()

@@ -276,23 +276,29 @@ def tile_partition(lat2, lon2, obs_lat, obs_lon, tile_deg=30.0, halo_km=900.0, m
 
 class BatchedFactor:
     """Lock-step factorization of many plans (``oisat_batch_potrf``): the plans are sorted by size and cut into groups of
-    comparable block count (a group's smallest matrix has at least ``ratio`` of the blocks of its largest), one batch and
-    one stream per group -- in a 720x1440 month: the two polar caps (137 blocks) and the 48 mid-latitude tiles (31-48)."""
+    comparable block count (a group's smallest matrix has at least ``ratio`` of the blocks of its largest) -- in a
+    720x1440 month: the 48 mid-latitude tiles (31-48 blocks) and the two polar caps (137 blocks).  The groups are
+    groups run side by side, one stream each (``OISAT_BATCH_SCHEDULE`` selects two other schedules that measured the same)."""
 
     def __init__(self, device: int, plans, ratio: float = 0.5):
-        self.groups = []
+        groups = []
         order = sorted((p for p in plans if p is not None), key=lambda p: -p.m)
         cur = []
         for p in order:
             if cur and p.mp < ratio * cur[0].mp:
-                self.groups.append(cur)
+                groups.append(cur)
                 cur = []
             cur.append(p)
         if cur:
-            self.groups.append(cur)
-        self.ctxs, self.ids = [], []
-        for g in self.groups:
-            ctx = _hip.Context(device).own_stream()
+            groups.append(cur)
+        self.groups = groups[::-1]                          # smallest systems first
+        # schedule (OISAT_BATCH_SCHEDULE): "concurrent" -- one stream per group, all groups at once, then the solves;
+        # "serial" -- one stream, group after group, then the solves; "interleave" -- one stream, and the lanes start a
+        # group's solves as soon as it is factored, underneath the next group's GEMMs
+        self.schedule = os.environ.get("OISAT_BATCH_SCHEDULE", "concurrent")
+        self.ctxs = [_hip.Context(device).own_stream() for _ in self.groups]
+        self.ids = []
+        for g, ctx in zip(self.groups, self.ctxs):
             n = len(g)
             Sp = (C.c_void_p * n)(*[p.S.ptr for p in g])
             Tp = (C.c_void_p * n)(*[p.tinv.ptr for p in g])
@@ -300,19 +306,33 @@ class BatchedFactor:
             ld = (C.c_int64 * n)(*[p.mp for p in g])
             bid = C.c_int(-1)
             ctx.check(ctx.lib.oisat_batch_create(ctx.h, n, Sp, mm, ld, Tp, C.byref(bid)))
-            self.ctxs.append(ctx)
             self.ids.append(bid.value)
+        self.group_of = {id(p): gi for gi, g in enumerate(self.groups) for p in g}
+        # measured (ms per run: 1 month / 4 months / 12 months of 720x1440, 1e5 obs): concurrent 92 / 281 / 761,
+        # serial 106 / 299 / 783, interleave 87 / 296 / 791 -- within noise of each other; concurrent is the default
 
-    def factor(self, check_pd=False):
-        """Every group's stream waits for the lanes that built its matrices, factors them, and the lanes wait for it."""
-        for g, ctx, bid in zip(self.groups, self.ctxs, self.ids):
+    def run(self, pool, per_lane_plans, refine, check_pd=False):
+        """``per_lane_plans[li]``: the plans of lane li in run order, already BUILT (their S enqueued on the lane)."""
+        prev = None
+        for gi, (g, ctx, bid) in enumerate(zip(self.groups, self.ctxs, self.ids)):
             lanes = list({id(p.ctx): p.ctx for p in g}.values())
             for lane in lanes:
                 ctx.wait_for(lane)
+            if prev is not None and self.schedule != "concurrent":
+                ctx.wait_for(prev)                          # group after group
             info = (C.c_int * 2)(0, -1)
             ctx.check(ctx.lib.oisat_batch_potrf(ctx.h, bid, info if check_pd else None))
-            for lane in lanes:
-                lane.wait_for(ctx)
+            prev = ctx
+            if self.schedule == "interleave":
+                for lane in lanes:
+                    lane.wait_for(ctx)
+                pool.enqueue([[(lambda p=p: p.run_solve(refine)) for p in plans if self.group_of[id(p)] == gi]
+                              for plans in per_lane_plans])
+        if self.schedule != "interleave":
+            for lane in pool.lanes:
+                for ctx in self.ctxs:
+                    lane.wait_for(ctx)
+            pool.enqueue([[(lambda p=p: p.run_solve(refine)) for p in plans] for plans in per_lane_plans])
 
     def check(self, what="batched factorization"):
         errors = []
@@ -326,8 +346,9 @@ class BatchedFactor:
 
     def close(self):
         for ctx, bid in zip(self.ctxs, self.ids):
-            ctx.lib.oisat_batch_destroy(ctx.h, bid)
-            ctx.close()
+            if ctx.h is not None:
+                ctx.lib.oisat_batch_destroy(ctx.h, bid)
+                ctx.close()
         self.ctxs, self.ids = [], []
 
 
@@ -543,8 +564,10 @@ class TiledAnalysis:
             self.pool.enqueue(self._per_lane(lambda p: p.run(L_km, refine=refine, check_pd=check_pd)))
             return
         self.pool.enqueue(self._per_lane(lambda p: p.run_build(L_km)))         # innovation, S = H B H^T + R
-        self.factor.factor(check_pd=check_pd)                                   # all tiles in lock-step
-        self.pool.enqueue(self._per_lane(lambda p: p.run_solve(refine)))        # gain solve, increment
+        plans = [[] for _ in self.lanes]
+        for ti in self._order:
+            plans[self._lane_of[ti]].append(self.plans[ti])
+        self.factor.run(self.pool, plans, refine, check_pd=check_pd)            # lock-step factor | gain solve, increment
 
     def run(self, L_km, refine=1, check_pd=False):
         """Enqueue every tile on its lane's stream (largest first), wait for all lanes and check their solve status:
@@ -657,8 +680,11 @@ class MonthTileBatch:
             return out
         if self.batched:
             self.pool.enqueue(per_lane(lambda p: p.run_build(L_km)))
-            self.factor.factor(check_pd=check_pd)
-            self.pool.enqueue(per_lane(lambda p: p.run_solve(refine)))
+            plans = [[] for _ in self.pool.lanes]
+            for key, ti in self._run_order:
+                ta = self.months[key]
+                plans[ta._lane_of[ti]].append(ta.plans[ti])
+            self.factor.run(self.pool, plans, refine, check_pd=check_pd)
         else:
             self.pool.enqueue(per_lane(lambda p: p.run(L_km, refine=refine, check_pd=check_pd)))
         if wait:
