@@ -328,6 +328,22 @@ int oisat_batch_potrf(oisat_ctx* h, int batch_id, int* info_host);
 int oisat_batch_destroy(oisat_ctx* h, int batch_id);
 int oisat_factor_adopt(oisat_ctx* h, const float* L, int64_t m, int64_t ld, float* tinv);
 
+/* ---- RCCL over xGMI: the two collectives of the sharded path ---------------------------------
+ * The reference runs one scheduler job per month and exchanges nothing (run/job_submitter_sbatch.py:45-68).  One
+ * process per GPU, (month x tile) units sharded statically: what is shared is broadcast once (the model grid), finished
+ * fields are gathered to the root -- there is no collective on the data path.  librccl is dlopen'ed at the first call
+ * (a copy already in the process, e.g. PyTorch's, is reused).  Enqueued on the handle's stream, asynchronous.
+ *   oisat_comm_unique_id  on ONE rank: 128 opaque bytes, to be handed to every rank by the launcher (file, env, MPI, ...)
+ *   oisat_comm_init       collective over all ranks: joins rank `rank` of `nranks`
+ *   oisat_comm_bcast      dev_buf (bytes) of `root` -> every rank's dev_buf, in place
+ *   oisat_comm_gather     every rank's `bytes` at send_dev -> recv_dev + r*bytes on `root` (recv_dev ignored elsewhere):
+ *                         a gather, not an all-gather -- only the root needs the fields */
+int oisat_comm_unique_id(char* id_out, int cap /* >= 128 */);
+int oisat_comm_init(oisat_ctx* h, int rank, int nranks, const char* unique_id);
+int oisat_comm_bcast(oisat_ctx* h, void* dev_buf, size_t bytes, int root);
+int oisat_comm_gather(oisat_ctx* h, const void* send_dev, size_t bytes, void* recv_dev, int root);
+int oisat_comm_destroy(oisat_ctx* h);
+
 /* Status of the dense solves enqueued on this handle since the last call with clear != 0 (synchronises the stream; one
  * 20-byte read-back).  oisat_potrf / oisat_gain_solve only report failures when given info_host / resid_host; an
  * unchecked (fully asynchronous) run records them here instead:

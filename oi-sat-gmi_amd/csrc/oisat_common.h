@@ -75,6 +75,8 @@ struct oisat_ctx {
     hipStream_t own_stream = nullptr;   // created by oisat_stream_create, destroyed at shutdown
     hipStream_t aux_stream = nullptr;   // look-ahead Cholesky: trailing updates run here, the panel chain on `stream`
     std::vector<hipEvent_t> sync_events;
+    void* comm = nullptr;               // RCCL communicator (oisat_comm_init), opaque here
+    int comm_rank = 0, comm_size = 1;
     hipEvent_t signal_event = nullptr;  // oisat_wait_for: recorded on this handle's stream, waited on by another handle's
     std::vector<ChBatch*> batches;      // oisat_batch_create
     // pinned host scratch for small synchronous read-backs

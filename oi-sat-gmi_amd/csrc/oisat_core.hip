@@ -39,9 +39,12 @@ extern "C" int oisat_init(int device_id, oisat_ctx** out) {
     return OISAT_OK;
 }
 
+extern "C" int oisat_comm_destroy(oisat_ctx* h);
+
 extern "C" void oisat_shutdown(oisat_ctx* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    if (h->comm) (void)oisat_comm_destroy(h);
     (void)hipDeviceSynchronize();
     for (auto& p : h->pending) {
         (void)hipEventDestroy(p.a);

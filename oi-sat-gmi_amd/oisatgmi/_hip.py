@@ -90,6 +90,11 @@ SIGNATURES = {
     "oisat_batch_potrf": (C.c_int, [_c_ctx, C.c_int, C.POINTER(C.c_int)]),
     "oisat_batch_destroy": (C.c_int, [_c_ctx, C.c_int]),
     "oisat_factor_adopt": (C.c_int, [_c_ctx, _ptr, _i64, _i64, _ptr]),
+    "oisat_comm_unique_id": (C.c_int, [C.c_char_p, C.c_int]),
+    "oisat_comm_init": (C.c_int, [_c_ctx, C.c_int, C.c_int, C.c_char_p]),
+    "oisat_comm_bcast": (C.c_int, [_c_ctx, _ptr, C.c_size_t, C.c_int]),
+    "oisat_comm_gather": (C.c_int, [_c_ctx, _ptr, C.c_size_t, _ptr, C.c_int]),
+    "oisat_comm_destroy": (C.c_int, [_c_ctx]),
     "oisat_solve_status": (C.c_int, [_c_ctx, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]),
     "oisat_dense_reserve": (C.c_int, [_c_ctx, _i64, _i64]),
 }

@@ -475,3 +475,27 @@ def test_batched_and_lane_serial_tiled_analyses_agree(ctx):
     assert np.abs(res[0][0] - res[1][0]).max() <= 2e-6 * scale
     assert np.abs(res[0][1] - res[1][1]).max() <= 2e-6 * scale
     assert np.abs(res[0][1]).max() > 1e-2 * scale
+
+
+def test_comm_entry_points_world_size_one(ctx):
+    """The RCCL entry points of the C-ABI (oisat_comm_*: broadcast of the shared grid, gather of finished fields) with a
+    communicator of one rank -- the only size a one-GPU box allows; the N > 1 logic of the sharded path runs over gloo in
+    tests/test_parallel_cpu.py."""
+    lib = ctx.lib
+    uid = C.create_string_buffer(128)
+    ctx.check(lib.oisat_comm_unique_id(uid, 128))
+    ctx.check(lib.oisat_comm_init(ctx.h, 0, 1, uid.raw))
+    try:
+        lat, lon = syn.global_grid(36, 72)
+        grid = ctx.upload(np.stack([lat, lon]))
+        ctx.check(lib.oisat_comm_bcast(ctx.h, grid.ptr, grid.nbytes, 0))
+        np.testing.assert_array_equal(ctx.download(grid.ptr, (2, 36, 72), np.float64), np.stack([lat, lon]))
+        field = np.random.default_rng(5).normal(size=(2, 36, 72)).astype(np.float32)
+        send = ctx.upload(field)
+        recv = ctx.alloc(field.nbytes)
+        ctx.check(lib.oisat_comm_gather(ctx.h, send.ptr, field.nbytes, recv.ptr, 0))
+        np.testing.assert_array_equal(ctx.download(recv.ptr, field.shape, np.float32), field)
+        assert lib.oisat_comm_gather(ctx.h, send.ptr, field.nbytes, None, 0) != 0       # the root needs a receive buffer
+        assert lib.oisat_comm_init(ctx.h, 0, 1, uid.raw) != 0                            # already joined
+    finally:
+        ctx.check(lib.oisat_comm_destroy(ctx.h))
