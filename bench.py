@@ -668,6 +668,20 @@ def main():
                                 "solve_tflops_end_to_end": dense.DenseAnalysis.flops(plan2.m) / (el2 / 20) / 1e12,
                                 "roofline": roof2, "kernel_ms_per_step": per2}
             del plan2
+        if not args.no_secondary and args.workload == DEFAULT and args.species == "NO2":
+            # BASELINE configs[4]: the other two species' parameter sets (control_omihcho.yml / control_omio3.yml shapes: value
+            # ranges, ctm_error, observation-error model) at the same full size -- one checked and two timed analyses each
+            sp_out = {}
+            for sp in ("HCHO", "O3"):
+                pl = make_plan(ctx, args.workload, 4000, lat2, lon2, sp)
+                rs = pl.run(L, refine=refine, check_pd=True, want_resid=True)
+                el = time_steps(lambda: pl.run(L, refine=refine), 2, 0, sync)
+                pl.check()
+                sp_out[sp] = {"ms_per_step": 1e3 * el / 2, "value": n * 2 / el, "unit": "grid-cells/s", "obs": pl.m,
+                              "refinement_residuals": rs,
+                              "solve_tflops_end_to_end": dense.DenseAnalysis.flops(pl.m) / (el / 2) / 1e12}
+                del pl
+            out["config5_species"] = sp_out
         if not args.no_secondary:
             out["tiled"] = tiled_leg(ctx, args.workload, sync)
             out["tier_a"] = tier_a_leg(ctx, ny, nx, nobs, sync)

@@ -560,6 +560,8 @@ class TiledAnalysis:
         return per_lane
 
     def enqueue(self, L_km, refine=1, check_pd=False):
+        if not self._order:                              # not a single observation in any owned tile: x_a = x_b
+            return
         if not self.batched:
             self.pool.enqueue(self._per_lane(lambda p: p.run(L_km, refine=refine, check_pd=check_pd)))
             return
@@ -678,7 +680,9 @@ class MonthTileBatch:
                 ta = self.months[key]
                 out[ta._lane_of[ti]].append(lambda p=ta.plans[ti]: fn(p))
             return out
-        if self.batched:
+        if not self._run_order:                          # this rank owns no unit with observations
+            pass
+        elif self.batched:
             self.pool.enqueue(per_lane(lambda p: p.run_build(L_km)))
             plans = [[] for _ in self.pool.lanes]
             for key, ti in self._run_order:

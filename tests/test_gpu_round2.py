@@ -499,3 +499,36 @@ def test_comm_entry_points_world_size_one(ctx):
         assert lib.oisat_comm_init(ctx.h, 0, 1, uid.raw) != 0                            # already joined
     finally:
         ctx.check(lib.oisat_comm_destroy(ctx.h))
+
+
+def test_tiled_analysis_with_empty_tiles_and_empty_shards(ctx):
+    """Tiles without a single observation are skipped (background kept, zero increment); a TiledAnalysis / MonthTileBatch
+    that owns no live unit at all -- a rank of a large job can end up with none -- runs and returns the background."""
+    p = syn.point_obs_case(36, 72, 40, 6161)
+    keep = (p.obs_lat > 0) & (p.obs_lon > 0) & (p.obs_lat < 50)          # observations in one corner only
+    o = {k: getattr(p, k)[keep] for k in ("obs_lat", "obs_lon", "obs_y", "obs_var")}
+    ta = dense.TiledAnalysis(p.lat, p.lon, tile_deg=30.0, halo_km=500.0, dtype=np.float32, streams=3)
+    ta.load(p.Xa, p.Sa, o["obs_lat"], o["obs_lon"], o["obs_y"], o["obs_var"])
+    assert 0 < len(ta.live) < len(ta.tiles)
+    ta.run(300.0, refine=1, check_pd=True)
+    xa, inc = ta.download()
+    dead = np.ones((36, 72), dtype=bool)
+    for ti in ta.live:
+        (y0, y1), (x0, x1) = ta.tiles[ti]["rows"], ta.tiles[ti]["cols"]
+        dead[y0:y1, x0:x1] = False
+    np.testing.assert_array_equal(xa[dead], p.Xa.astype(np.float32)[dead])
+    assert (inc[dead] == 0).all() and np.abs(inc[~dead]).max() > 0
+    # nothing owned at all
+    tb = dense.TiledAnalysis(p.lat, p.lon, tile_deg=30.0, halo_km=500.0, dtype=np.float32, pool=ta.pool)
+    tb.load(p.Xa, p.Sa, o["obs_lat"], o["obs_lon"], o["obs_y"], o["obs_var"], only=[])
+    tb.run(300.0, refine=1)
+    xb, incb = tb.download()
+    np.testing.assert_array_equal(xb, p.Xa.astype(np.float32))
+    assert (incb == 0).all()
+    ta.close()
+    mb = dense.MonthTileBatch(p.lat, p.lon, tile_deg=30.0, halo_km=500.0, dtype=np.float32, streams=2)
+    mb.add_month(0, p.Xa, p.Sa, o["obs_lat"], o["obs_lon"], o["obs_y"], o["obs_var"], only=[])
+    mb.build(min_slab_elems=64)
+    mb.run(300.0, refine=1)
+    assert mb.units == [] and (mb.download_slab() == 0).all()
+    mb.close()
