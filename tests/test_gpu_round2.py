@@ -532,3 +532,53 @@ def test_tiled_analysis_with_empty_tiles_and_empty_shards(ctx):
     mb.run(300.0, refine=1)
     assert mb.units == [] and (mb.download_slab() == 0).all()
     mb.close()
+
+
+def test_oi_tiled_mode_full_size_through_the_facade(ctx):
+    """BASELINE configs[2] through the reference's call surface: oisatgmi.oi(sensor, error_ctm) in `tiled` mode on a
+    720x1440 month with 1e5 observed cells -- localised block-B (polar caps + 30 deg tiles, halo 3 L), prior-error scaling
+    from the reference's knee sweep, all four attributes of driver.py:110-114 filled.  Checked at full size through
+    properties: the increment of sampled tiles against the float64 oracle contraction with the tile's own observation set,
+    0 <= AK <= 1 at observed cells, posterior error below the (scaled) prior error everywhere, NaN convention."""
+    c = syn.diag_case(720, 1440, 100000, 3001)
+    lat, lon = syn.global_grid(720, 1440)
+    o = oisatgmi()
+    o.ctm_averaged_vcd, o.sat_averaged_vcd = c.Xa.copy(), c.Y.copy()
+    o.sat_averaged_error = np.sqrt(c.So)
+    o.grid_lat, o.grid_lon = lat, lon
+    o.oi_mode, o.corr_length_km, o.tile_deg, o.oi_unobserved = "tiled", 300.0, 30.0, "xa"
+    o.oi("OMI", error_ctm=50.0)
+    s = o.oi_info["scale"]
+    assert o.oi_info["mode"] == "tiled" and o.oi_info["nobs"] > 95000 and 0.1 <= s <= 9.9
+    Y = np.where(c.Y < 0, 0.0, c.Y)
+    obs = np.isfinite(Y) & np.isfinite(c.So)
+    xb, inc, ak, err = o.ctm_averaged_vcd_corrected, o.increment_OI, o.ak_OI, o.error_OI
+    for a in (xb, inc, ak, err):
+        assert a.shape == (720, 1440) and np.isfinite(a).all()
+    prior = np.sqrt(s) * 0.5 * np.abs(c.Xa)
+    assert (err <= prior * (1 + 1e-5) + 1e-7).all()
+    assert (ak[obs] > -1e-4).all() and (ak[obs] < 1 + 1e-4).all() and (ak[~obs] == 0).all()
+    np.testing.assert_allclose(xb, c.Xa + inc, rtol=0, atol=1e-5 * np.abs(c.Xa).max())
+    # sampled tiles against the oracle: same tile partition, same observation sets
+    cell = np.flatnonzero(obs.ravel())
+    olat, olon = lat.ravel()[cell], lon.ravel()[cell]
+    tiles = dense.tile_partition(lat, lon, olat, olon, 30.0, 900.0)
+    sb = np.sqrt(s) * 0.5 * np.abs(c.Xa).ravel()
+    d_all = Y.ravel()[cell] - c.Xa.ravel()[cell]
+    rng = np.random.default_rng(4)
+    scale = np.abs(c.Xa).max()
+    import scipy.linalg as sla
+    for ti in (5, 17, 30, 44):                                   # four mid-latitude tiles (4,000-6,000 observations each)
+        t = tiles[ti]
+        ob = t["obs"]
+        po = orc.unit_vectors(olat[ob], olon[ob])
+        so = sb[cell[ob]]
+        S = orc.gaussian_corr(po, po, 300.0) * so[:, None] * so[None, :]
+        S[np.diag_indices_from(S)] += c.So.ravel()[cell[ob]]
+        z = sla.cho_solve(sla.cho_factor(S, lower=True, overwrite_a=True), d_all[ob])
+        (y0, y1), (x0, x1) = t["rows"], t["cols"]
+        iy, ix = rng.integers(y0, y1, 60), rng.integers(x0, x1, 60)
+        cells = iy * 1440 + ix
+        pg = orc.unit_vectors(lat.ravel()[cells], lon.ravel()[cells])
+        inc_ref = sb[cells] * (orc.gaussian_corr(pg, po, 300.0) @ (so * z))
+        assert np.abs(inc.ravel()[cells] - inc_ref).max() <= 1e-5 * scale, ti
