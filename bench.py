@@ -642,8 +642,7 @@ def main():
                 bplans.append(q)
             bf = dense.BatchedFactor(ctx.device, bplans)
 
-            bpool = dense.LanePool.__new__(dense.LanePool)          # the eight handles above as a pool (no new streams)
-            bpool.ctx, bpool.lanes, bpool.factors, bpool._threads = ctx, blanes, [], None
+            bpool = dense.LanePool.from_lanes(blanes)               # the eight handles above as a pool (no new streams)
 
             def months_batched():
                 for q in bplans:

@@ -182,6 +182,9 @@ class DenseAnalysis:
         c.check(lib.oisat_cov_build(h, self.oxyz.ptr, self.osig.ptr, self.ovar.ptr, self.m, g, self.S.ptr, self.mp))
 
     def run_solve(self, refine: int = 2):
+        if self.tinv is None:
+            raise ValueError("run_build / run_solve belong to plans created with batched=True (they own their inverted "
+                             "diagonal blocks); use run() for a plan that factors on its own handle")
         c, lib, h = self.ctx, self.ctx.lib, self.ctx.h
         m, ld, g = self.m, self.mp, self._g
         item = self.dt.itemsize
@@ -387,6 +390,16 @@ class LanePool:
         self.factors = [SharedFactor(lane) for lane in self.lanes]
         self._threads = None
 
+    @classmethod
+    def from_lanes(cls, lanes):
+        """A pool over handles the caller already has (each with its own stream); ``close`` leaves them open."""
+        self = cls.__new__(cls)
+        self.ctx, self.lanes = lanes[0], list(lanes)
+        self.factors = [SharedFactor(lane) for lane in self.lanes]
+        self._threads = None
+        self._borrowed = True
+        return self
+
     def __len__(self):
         return len(self.lanes)
 
@@ -447,6 +460,8 @@ class LanePool:
         for f in self.factors:
             if f.buf is not None:
                 f.buf.free()
+        if getattr(self, "_borrowed", False):
+            return
         for lane in self.lanes[1:]:
             lane.close()
 
