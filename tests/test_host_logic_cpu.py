@@ -112,3 +112,64 @@ def test_savedaily_writes_the_reference_files(tmp_path):
     m = loadmat(str(tmp_path / "daily" / files[1]))
     assert set(("vcd_sat", "vcd_ctm", "vcd_err", "time_sat", "lat", "lon")) <= set(m)
     np.testing.assert_array_equal(m["vcd_ctm"], np.full((3, 4), 4.0))
+
+
+def test_oi_mode_settings_are_read_from_attributes_then_environment(monkeypatch):
+    """The analysis-mode switches of oisatgmi.oi() (driver.py:108-114 keeps its signature): an attribute on the instance
+    wins over the environment, which wins over the default; a bad value is refused before anything touches the GPU."""
+    import pytest
+    o = oisatgmi()
+    assert o._oi_setting("oi_mode", "OISAT_OI_MODE", "diag") == "diag"
+    monkeypatch.setenv("OISAT_OI_MODE", "tiled")
+    monkeypatch.setenv("OISAT_CORR_LENGTH_KM", "450")
+    assert o._oi_setting("oi_mode", "OISAT_OI_MODE", "diag") == "tiled"
+    assert o._oi_setting("corr_length_km", "OISAT_CORR_LENGTH_KM", 300.0, float) == 450.0
+    o.oi_mode, o.corr_length_km = "dense", 120
+    assert o._oi_setting("oi_mode", "OISAT_OI_MODE", "diag") == "dense"
+    assert o._oi_setting("corr_length_km", "OISAT_CORR_LENGTH_KM", 300.0, float) == 120.0
+    o.ctm_averaged_vcd = np.ones((4, 8))
+    o.sat_averaged_vcd = np.ones((4, 8))
+    o.sat_averaged_error = np.ones((4, 8))
+    o.oi_mode = "banana"
+    with pytest.raises(ValueError, match="diag, dense or tiled"):
+        o.oi("OMI")
+    # the model grid: explicit attributes, else the first granule's centres (as output_fields does, driver.py:190-195)
+    lat, lon = syn.global_grid(4, 8)
+    o.grid_lat, o.grid_lon = lat, lon
+    np.testing.assert_array_equal(o._oi_grid()[0], lat)
+    o2 = oisatgmi()
+
+    class R:
+        pass
+    o2.reader_obj = R()
+    o2.reader_obj.sat_data = [None, syn.granule_stack(4, 8, 2, 1)[0]]
+    np.testing.assert_array_equal(o2._oi_grid()[1], o2.reader_obj.sat_data[1].longitude_center)
+
+
+def test_tile_partition_polar_caps_and_halo():
+    """dense.tile_partition: every cell in exactly one tile; a band whose halo reaches the pole is ONE cap tile holding every
+    observation of the band (+ halo); cutting it by longitude instead gives tiles with that same observation set each."""
+    lat, lon = syn.global_grid(36, 72)
+    rng = np.random.default_rng(3)
+    olat, olon = rng.uniform(-89, 89, 3000), rng.uniform(-180, 180, 3000)
+    merged = dense.tile_partition(lat, lon, olat, olon, 30.0, 900.0)
+    cut = dense.tile_partition(lat, lon, olat, olon, 30.0, 900.0, merge_polar=False)
+    assert len(cut) == 6 * 12 and len(merged) == 1 + 4 * 12 + 1
+    cover = np.zeros((36, 72), dtype=int)
+    for t in merged:
+        cover[t["rows"][0]:t["rows"][1], t["cols"][0]:t["cols"][1]] += 1
+    assert (cover == 1).all()
+    south = merged[0]
+    assert south["cols"] == (0, 72) and south["rows"] == (0, 6)
+    for t in cut[:12]:
+        np.testing.assert_array_equal(np.sort(t["obs"]), np.sort(south["obs"]))
+    h = np.rad2deg(900.0 / dense.EARTH_RADIUS_KM)
+    assert set(south["obs"]) == set(np.flatnonzero(olat <= -60.0 + h))
+    # a mid-latitude tile: everything inside it is there, nothing farther than the halo (in latitude) is
+    t = merged[1 + 12 + 5]
+    (y0, y1), (x0, x1) = t["rows"], t["cols"]
+    la0, la1 = lat[y0, 0] - 2.5, lat[y1 - 1, 0] + 2.5
+    lo0, lo1 = lon[0, x0] - 2.5, lon[0, x1 - 1] + 2.5
+    inside = (olat >= la0) & (olat <= la1) & (olon >= lo0) & (olon <= lo1)
+    assert np.isin(np.flatnonzero(inside), t["obs"]).all()
+    assert (olat[t["obs"]] >= la0 - h - 1e-9).all() and (olat[t["obs"]] <= la1 + h + 1e-9).all()
