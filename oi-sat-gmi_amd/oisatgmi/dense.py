@@ -438,8 +438,10 @@ class LanePool:
             for fn in fns:
                 fn()
         futures = [self._threads.submit(drive, li, fns) for li, fns in work]
-        for f in futures:
-            f.result()                                   # re-raises a worker's exception
+        errors = [f.exception() for f in futures]        # waits for EVERY lane before anything is raised
+        for e in errors:
+            if e is not None:
+                raise e
 
     def check(self, what="tiled analysis"):
         """Wait for every lane and read (and clear) every lane's solve status before raising, so that one failed unit
