@@ -187,13 +187,18 @@ class DeviceBuffer:
     def __init__(self, ctx: "Context", nbytes: int):
         self.ctx = ctx
         self.nbytes = int(nbytes)
+        cached = ctx._take_cached(self.nbytes)
+        if cached is not None:
+            self.ptr = cached
+            return
         p = _ptr()
         ctx.check(ctx.lib.oisat_dmalloc(ctx.h, max(self.nbytes, 16), C.byref(p)))
         self.ptr = p.value
 
     def free(self):
         if self.ptr is not None and self.ctx is not None and self.ctx.h is not None:
-            self.ctx.lib.oisat_dfree(self.ctx.h, self.ptr)
+            if not self.ctx._give_cached(self.nbytes, self.ptr):
+                self.ctx.lib.oisat_dfree(self.ctx.h, self.ptr)
         self.ptr = None
 
     def __del__(self):
@@ -218,6 +223,46 @@ class Context:
             raise OisatUnavailable(f"oisat_init(device={device}) failed: {msg}.  This package has no CPU fallback.")
         self.h = h
         self.device = int(device)
+        # Freed buffers of up to 256 MB are parked (2 GB at most) and handed out again for a request of exactly the same
+        # size: the drop-in calls (OI, averaging, interpolator) allocate the same handful of sizes on every call, and a
+        # hipMalloc / hipFree pair costs more than the kernels they bracket.  One stream per handle, so a reused buffer
+        # is always ordered behind whatever last touched it.
+        self._cache = {}
+        self._cache_bytes = 0
+        self._cache_lock = threading.Lock()
+
+    _CACHE_MAX_BUFFER = 256 << 20
+    _CACHE_MAX_TOTAL = 2 << 30
+
+    def _take_cached(self, nbytes):
+        with self._cache_lock:
+            lst = self._cache.get(nbytes)
+            if lst:
+                self._cache_bytes -= nbytes
+                return lst.pop()
+        return None
+
+    def _give_cached(self, nbytes, ptr) -> bool:
+        if nbytes <= 0 or nbytes > self._CACHE_MAX_BUFFER or os.environ.get("OISAT_BUFFER_CACHE", "1") == "0":
+            return False
+        try:
+            self.sync()                  # what hipFree would have waited for on this handle's stream
+        except OisatError:
+            return False
+        with self._cache_lock:
+            if self._cache_bytes + nbytes > self._CACHE_MAX_TOTAL:
+                return False
+            self._cache.setdefault(nbytes, []).append(ptr)
+            self._cache_bytes += nbytes
+        return True
+
+    def drop_cache(self):
+        with self._cache_lock:
+            for lst in self._cache.values():
+                for ptr in lst:
+                    self.lib.oisat_dfree(self.h, ptr)
+            self._cache.clear()
+            self._cache_bytes = 0
 
     # ---- plumbing
     def check(self, rc: int):
@@ -226,6 +271,7 @@ class Context:
 
     def close(self):
         if self.h is not None:
+            self.drop_cache()
             self.lib.oisat_shutdown(self.h)
             self.h = None
 
