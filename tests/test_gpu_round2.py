@@ -582,3 +582,49 @@ def test_oi_tiled_mode_full_size_through_the_facade(ctx):
         pg = orc.unit_vectors(lat.ravel()[cells], lon.ravel()[cells])
         inc_ref = sb[cells] * (orc.gaussian_corr(pg, po, 300.0) @ (so * z))
         assert np.abs(inc.ravel()[cells] - inc_ref).max() <= 1e-5 * scale, ti
+
+
+@pytest.mark.parametrize("M,N,K,lower,mode", [
+    (1024, 1024, 160, 0, 0),        # 64 tiles: 64x64-tile kernel
+    (4096, 4096, 96, 1, 0),         # 528 lower tiles > 512 slots: persistent gemm_nt_kernel, some workgroups take two tiles
+    (12800, 1024, 64, 0, 1),        # 800 tiles, C = A B^T
+    (9216, 9216, 32, 1, 0),         # 2628 lower tiles, a single K-step per tile: the cross-tile pipeline with nkt = 1
+    (6144, 6144, 2048, 1, 0),       # 1176 lower tiles, K >= 2048: gemm_nt_big_kernel
+])
+def test_gemm_nt_kernels_against_float64(ctx, M, N, K, lower, mode):
+    """oisat_gemm_nt through its three kernels (64x64 tiles, the persistent pipelined-across-tiles kernel with the C tile
+    prefetched, the one-tile kernel for K >= 2048) against a float64 product; in `lower` mode only tiles on or below the
+    diagonal are defined."""
+    rng = np.random.default_rng(M + N + K)
+    A = rng.uniform(-1, 1, (M, K)).astype(np.float32)
+    B = rng.uniform(-1, 1, (N, K)).astype(np.float32)
+    C0 = rng.uniform(-1, 1, (M, N)).astype(np.float32)
+    a, b, c = ctx.upload(A), ctx.upload(B), ctx.upload(C0)
+    ctx.check(ctx.lib.oisat_gemm_nt(ctx.h, c.ptr, N, a.ptr, K, b.ptr, K, M, N, K, mode, lower))
+    out = ctx.download(c.ptr, (M, N), np.float32)
+    ref = A.astype(np.float64) @ B.astype(np.float64).T
+    ref = C0 - ref if mode == 0 else ref
+    if lower:                                    # defined on / below the diagonal at 64-row granularity (include/oisat.h)
+        ti, tj = np.meshgrid(np.arange(M) // 64, np.arange(N) // 64, indexing="ij")
+        keep = ti >= tj
+    else:
+        keep = np.ones((M, N), dtype=bool)
+    assert np.abs(out - ref)[keep].max() <= 4e-6 * np.sqrt(K) * max(1.0, np.abs(ref).max() / np.sqrt(K))
+    # strictly-upper 128-tiles are never touched
+    if lower:
+        far = (np.arange(N)[None, :] // 128) > (np.arange(M)[:, None] // 128)
+        np.testing.assert_array_equal(out[far], C0[far])
+
+
+def test_gemm_nt_in_place_trsm_form_many_tiles(ctx):
+    """C aliases A with N = K = 128 (TRSM-as-GEMM, P <- P T^T) on 800 row tiles: the persistent kernel prefetches the next
+    tile's rows before the current tile's stores -- different rows, no hazard."""
+    rng = np.random.default_rng(5)
+    M = 128 * 800
+    P = rng.uniform(-1, 1, (M, 128)).astype(np.float32)
+    T = np.tril(rng.uniform(-1, 1, (128, 128))).astype(np.float32)
+    p, t = ctx.upload(P), ctx.upload(T)
+    ctx.check(ctx.lib.oisat_gemm_nt(ctx.h, p.ptr, 128, p.ptr, 128, t.ptr, 128, M, 128, 128, 1, 0))
+    out = ctx.download(p.ptr, (M, 128), np.float32)
+    ref = P.astype(np.float64) @ T.astype(np.float64).T
+    assert np.abs(out - ref).max() <= 2e-5
