@@ -628,3 +628,47 @@ def test_gemm_nt_in_place_trsm_form_many_tiles(ctx):
     out = ctx.download(p.ptr, (M, 128), np.float32)
     ref = P.astype(np.float64) @ T.astype(np.float64).T
     assert np.abs(out - ref).max() <= 2e-5
+
+
+def test_config4_units_at_full_size_on_one_gpu(ctx):
+    """BASELINE configs[3] at full size, as one rank sees it: a MonthTileBatch over an LPT shard of the (month x tile) units
+    of two 720x1440 / 1e5-observation months (every second unit, as a 2-rank partition would hand out) against each
+    month's own TiledAnalysis -- every owned tile equal to refinement accuracy, unit bookkeeping (offsets, shapes, slab)
+    consistent with parallel.partition_units."""
+    from oisatgmi import parallel
+    L = 300.0
+    lat, lon = syn.global_grid(720, 1440)
+    months = {k: syn.point_obs_case(720, 1440, 100000, 4000 + k, swaths=True) for k in range(2)}
+    units, weights = [], []
+    for k, p in months.items():
+        for ti, t in enumerate(dense.tile_partition(lat, lon, p.obs_lat, p.obs_lon, 30.0, 3 * L)):
+            if t["obs"].size:
+                units.append((k, ti))
+                weights.append(float(t["obs"].size) ** 3)
+    parts = parallel.partition_units(len(units), 2, weights)
+    assert abs(sum(weights[i] for i in parts[0]) / sum(weights[i] for i in parts[1]) - 1.0) < 0.01
+    mine = parts[1]
+    batch = dense.MonthTileBatch(lat, lon, 30.0, 3 * L, np.float32, streams=12)
+    for k, p in months.items():
+        only = [units[i][1] for i in mine if units[i][0] == k]
+        batch.add_month(k, p.Xa, p.Sa, p.obs_lat, p.obs_lon, p.obs_y, p.obs_var, only=only)
+    batch.build()
+    assert sorted((k, ti) for k, ti, _ in batch.units) == sorted(units[i] for i in mine)
+    batch.run(L, refine=1, check_pd=True)
+    slab = batch.download_slab()
+    assert np.isfinite(slab).all()
+    for k, p in months.items():
+        ta = dense.TiledAnalysis(lat, lon, tile_deg=30.0, halo_km=3 * L, dtype=np.float32)
+        ta.load(p.Xa, p.Sa, p.obs_lat, p.obs_lon, p.obs_y, p.obs_var)
+        ta.run(L, refine=1)
+        xa, inc = ta.download()
+        ta.close()
+        tol = 5e-6 * np.abs(p.Xa).max()
+        for u, (key, ti, _) in enumerate(batch.units):
+            if key != k:
+                continue
+            (y0, y1), (x0, x1) = ta.tiles[ti]["rows"], ta.tiles[ti]["cols"]
+            shape = batch.unit_shape(u)
+            got = slab[batch.offsets[u]: batch.offsets[u] + int(np.prod(shape))].reshape(shape)
+            assert np.abs(got[0] - xa[y0:y1, x0:x1]).max() <= tol and np.abs(got[1] - inc[y0:y1, x0:x1]).max() <= tol, (k, ti)
+    batch.close()
