@@ -6,10 +6,9 @@
 //
 // HBM layout: four (ny*nx) fields of T in, four out, all contiguous; nothing else.
 // The sweep never materialises the 99x3 temporaries the reference keeps alive: a wave loads 64
-// cells coalesced, then walks them with lane == scaling (lanes 0..63 own scale `lane`, and scale
-// `lane+64`), broadcasting one cell at a time with v_readlane.  Every lane therefore accumulates
-// its own two (sum, count) pairs in double with NO cross-lane reduction; a second tiny kernel adds
-// the per-wave partials in wave order.  The launch shape is fixed, so the 99 means are bitwise
+// cells coalesced, then walks them two at a time with lanes == scalings (three per lane and half-wave,
+// see oi_curve_kernel), broadcasting the cells with v_readlane.  Every lane accumulates its own
+// (sum, count) pairs in double; a second tiny kernel adds the per-block partials in block order.  The launch shape is fixed, so the 99 means are bitwise
 // reproducible run to run -- the knee pick that follows is sensitive to 1-ulp changes.
 //
 // Built with -ffp-contract=off: the operation order below is the reference's, one rounding each.
@@ -44,48 +43,94 @@ __device__ __forceinline__ double bcast<double>(double v, int src_lane) {
     return __builtin_bit_cast(double, r);
 }
 
+// Lane layout of the sweep.  99 scalings on 64 lanes: with lane == scaling (two slots per lane, round 1) 29 of every 128
+// lane-slots idle.  Here a wave walks its 64 cells TWO at a time -- lanes 0-31 take cell 2j, lanes 32-63 cell 2j+1 --
+// and every lane of a half owns three scalings (l, l+32, l+64: 96 of them, all slots busy); the remaining scalings
+// (96, 97, 98 of the reference's 99) are then evaluated with lane == cell and summed over the wave by a fixed xor
+// tree, lane k keeping the running total of scaling 96+k.  Same arithmetic per (cell, scaling), 99 x 64 evaluations per
+// 64 cells instead of 128 x 64; sums still in double, fixed launch shape and fixed combination order => reproducible.
+constexpr int kMainScales = 96;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+__device__ __forceinline__ unsigned wave_sum(unsigned v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+
 template <typename T>
 __global__ __launch_bounds__(kCurveThreads) void oi_curve_kernel(const T* __restrict__ Sa, const T* __restrict__ So,
                                                                   int64_t n, const double* __restrict__ scales,
                                                                   int nscales, double* __restrict__ part_sum,
                                                                   unsigned* __restrict__ part_cnt) {
     const int lane = threadIdx.x & (kWave - 1);
+    const int half = lane >> 5, l = lane & 31;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const bool has0 = lane < nscales;
-    const bool has1 = lane + kWave < nscales;
-    const T s0 = has0 ? (T)scales[lane] : T(1);
-    const T s1 = has1 ? (T)scales[lane + kWave] : T(1);
-    double acc0 = 0.0, acc1 = 0.0;
-    unsigned c0 = 0, c1 = 0;
+    const int nmain = nscales < kMainScales ? nscales : kMainScales;
+    const int nleft = nscales - nmain;                                  // scalings 96.. : lane == cell
+    bool has[3];
+    T sc[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        has[q] = l + 32 * q < nmain;
+        sc[q] = has[q] ? (T)scales[l + 32 * q] : T(1);
+    }
+    double acc[3] = {0.0, 0.0, 0.0};
+    unsigned cn[3] = {0u, 0u, 0u};
+    double lacc = 0.0;                                                  // lane k: running sum of scaling 96 + k
+    unsigned lcn = 0u;
     for (int64_t base = wave * kWave; base < n; base += (int64_t)kCurveWaves * kWave) {
         const int64_t i = base + lane;
         const T a = i < n ? Sa[i] : nan_of<T>();
         const T o = i < n ? So[i] : nan_of<T>();
         const int cnt = (n - base) < kWave ? (int)(n - base) : kWave;
-        for (int j = 0; j < cnt; ++j) {
-            const T aj = bcast<T>(a, j);
-            const T oj = bcast<T>(o, j);
-            const T ak0 = ak_of<T>(aj, oj, s0);
-            if (ak0 == ak0) { acc0 += (double)ak0; ++c0; }
-            if (nscales > kWave) {
-                const T ak1 = ak_of<T>(aj, oj, s1);
-                if (ak1 == ak1) { acc1 += (double)ak1; ++c1; }
+        for (int j = 0; 2 * j < cnt; ++j) {
+            const T a0 = bcast<T>(a, 2 * j), o0 = bcast<T>(o, 2 * j);
+            const T a1 = bcast<T>(a, 2 * j + 1), o1 = bcast<T>(o, 2 * j + 1);
+            const T aj = half ? a1 : a0, oj = half ? o1 : o0;
+            const bool live = 2 * j + half < cnt;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const T ak = ak_of<T>(aj, oj, sc[q]);
+                if (live && ak == ak) { acc[q] += (double)ak; ++cn[q]; }
             }
         }
+        for (int k = 0; k < nleft; ++k) {                               // wave-uniform trip count
+            const T ak = ak_of<T>(a, o, (T)scales[nmain + k]);
+            const bool ok = i < n && ak == ak;
+            const double s = wave_sum(ok ? (double)ak : 0.0);
+            const unsigned c = wave_sum(ok ? 1u : 0u);
+            if (lane == k) { lacc += s; lcn += c; }
+        }
     }
-    // the block's four waves are combined here in wave order (fixed => reproducible): one partial per block
-    __shared__ double bs[kCurveThreads / kWave][OISAT_MAX_SCALES];
-    __shared__ unsigned bc[kCurveThreads / kWave][OISAT_MAX_SCALES];
+    // the block's four waves (x two halves) are combined here in a fixed order (=> reproducible): one partial per block
+    __shared__ double bs[2 * kCurveThreads / kWave][OISAT_MAX_SCALES];
+    __shared__ unsigned bc[2 * kCurveThreads / kWave][OISAT_MAX_SCALES];
     const int wv = threadIdx.x >> 6;
-    bs[wv][lane] = has0 ? acc0 : 0.0;
-    bs[wv][kWave + lane] = has1 ? acc1 : 0.0;
-    bc[wv][lane] = has0 ? c0 : 0u;
-    bc[wv][kWave + lane] = has1 ? c1 : 0u;
+    for (int k = threadIdx.x; k < 2 * (kCurveThreads / kWave) * OISAT_MAX_SCALES; k += kCurveThreads) {
+        (&bs[0][0])[k] = 0.0;
+        (&bc[0][0])[k] = 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        if (has[q]) {
+            bs[2 * wv + half][l + 32 * q] = acc[q];
+            bc[2 * wv + half][l + 32 * q] = cn[q];
+        }
+    if (lane < nleft) {
+        bs[2 * wv][nmain + lane] = lacc;
+        bc[2 * wv][nmain + lane] = lcn;
+    }
     __syncthreads();
     if (threadIdx.x < OISAT_MAX_SCALES) {
         double S = bs[0][threadIdx.x];
         unsigned Cn = bc[0][threadIdx.x];
-        for (int k = 1; k < kCurveThreads / kWave; ++k) { S += bs[k][threadIdx.x]; Cn += bc[k][threadIdx.x]; }
+        for (int k = 1; k < 2 * (kCurveThreads / kWave); ++k) { S += bs[k][threadIdx.x]; Cn += bc[k][threadIdx.x]; }
         part_sum[(int64_t)blockIdx.x * OISAT_MAX_SCALES + threadIdx.x] = S;
         part_cnt[(int64_t)blockIdx.x * OISAT_MAX_SCALES + threadIdx.x] = Cn;
     }
