@@ -631,8 +631,65 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int LDA = 130;
 constexpr size_t kDiagShm = sizeof(float) * (NB * LDA + NB);
 
-__device__ __forceinline__ float rdlane(float v, int l) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+// Factor and invert a 16x16 diagonal block in ONE sweep, in registers.  Lane r of every 16-lane row holds row r of the
+// block (d[c] = A[r][c]) and column r of the running inverse (x[c] = X[c][r], X = L^-1, starts as I): after pivot step k
+// column k of L is final, which is exactly what the forward substitution for X needs next, so each broadcast
+// L[c][k] = d[k] of lane c feeds both the factor's trailing update and the inverse's running sums.
+// The broadcast is the DPP operand of the FMA itself (row_newbcast:c = lane c of each 16-lane row, gfx90a+):
+//     d[c] += (-d[k] @ lane c) * d[k]        x[c] += (-d[k] @ lane c) * x[k]        (v_fmac_f32_dpp)
+// two vector instructions per (k, c) and no scalar registers.  (Rounds 1-2 broadcast through v_readlane: 240 scalar
+// values live across the unrolled sweep, which the compiler spilled to VGPR lanes with ~350 v_writelane / ~640
+// v_readlane -- 310 cycles per pivot; the builtin DPP move is not folded into the FMA by the compiler either, hence
+// the inline assembly.)  Hazard: a VGPR written by a VALU instruction may be read through DPP two wait states later at
+// the earliest and the compiler does not see into the asm blocks -- diag16_settle() puts the s_nop between the
+// instruction that finishes column k and its DPP readers, and every asm block here is volatile, i.e. stays in order.
+template <int C>
+__device__ __forceinline__ float row16_bcast_settled(float v) {          // v was last written by one of the asm blocks
+    float o;
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(v), "n"(C));
+    return o;
+}
+
+__device__ __forceinline__ void diag16_settle(float& dk, float& xk) {
+    asm volatile("s_nop 1" : "+v"(dk), "+v"(xk));
+}
+
+template <int K, int C>
+__device__ __forceinline__ void diag16_columns(float (&d)[16], float (&x)[16]) {
+    if constexpr (C < 16) {
+        asm volatile("v_fmac_f32_dpp %0, -%2, %2 row_newbcast:%4 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f32_dpp %1, -%2, %3 row_newbcast:%4 row_mask:0xf bank_mask:0xf"
+                     : "+v"(d[C]), "+v"(x[C]) : "v"(d[K]), "v"(x[K]), "n"(C));
+        diag16_columns<K, C + 1>(d, x);
+    }
+}
+
+template <int K>
+__device__ __forceinline__ void diag16_pivots(float (&d)[16], float (&x)[16], int r, int& bad) {
+    if constexpr (K < 16) {
+        float piv = row16_bcast_settled<K>(d[K]);
+        const bool neg = !(piv > 0.f);
+        bad = (neg && bad == 0) ? K + 1 : bad;
+        piv = neg ? 1.f : piv;
+        float ri = __builtin_amdgcn_rsqf(piv);
+        ri = ri * (1.5f - 0.5f * piv * ri * ri);          // one Newton step: ~0.5 ulp
+        d[K] = (r == K) ? piv * ri : d[K] * ri;           // L[k][k] = sqrt(piv); column k of L
+        x[K] = (K >= r) ? x[K] * ri : 0.f;                // X[k][:] /= L[k][k]
+        if constexpr (K < 15) {
+            diag16_settle(d[K], x[K]);
+            diag16_columns<K, K + 1>(d, x);
+        }
+        diag16_pivots<K + 1>(d, x, r, bad);
+    }
+}
+
+__device__ __forceinline__ void diag16_report(int bad, int* info, int col0, int lane) {
+    if (bad && lane == 0) {               // info[0]: this factorization; info[1], info[2]: sticky (first column, count)
+        atomicCAS(info, 0, col0 + bad);  //          until oisat_solve_status clears them
+        atomicCAS(info + 1, 0, col0 + bad);
+        atomicAdd(info + 2, 1);
+        atomicCAS(info + 3, 0, (int)blockIdx.x + 1);   // batched factorization: which matrix of the table (1-based)
+    }
 }
 
 // element (k, j) of a lower-triangular inverse block whose strictly-lower part is stored transposed above the diagonal of
@@ -642,52 +699,23 @@ __device__ __forceinline__ float tri_t(const float* a, const float* tdiag, int o
     return k > j ? off : (k == j ? tdiag[o + j] : 0.f);
 }
 
-// Factor and invert a 16x16 diagonal block in ONE sweep on one wave.  Lanes 0-15 hold the rows of the block
-// (v[c] = A[r][c]), lanes 16-31 the columns of the running inverse (v[c] = X[c][r], X = L^-1, starts as I): after pivot
-// step k column k of L is final, which is exactly what the forward substitution for X needs next, and BOTH updates
-// are the same instruction, v[c] -= v[k] * L[c][k] -- the factor's trailing update on lanes 0-15, the inverse's running
-// sums on lanes 16-31 -- with L[c][k] broadcast by v_readlane from lane c.  (Round 1 ran the two updates one after the
-// other on the same 16 lanes: twice the FMAs on the serial path.)
+// One-image form: L goes to the lower part of the block, X = L^-1 transposed to the strictly upper part, its diagonal
+// to tdiag (see tri_t).
 __device__ __forceinline__ void diag16_factor_invert(float* a, float* tdiag, int j0, int* info, int col0, int lane) {
     const int r = lane & 15;
-    const bool inv = (lane & 16) != 0;                     // lanes 32-63 mirror 0-31 (never stored)
-    float v[16];
+    float d[16], x[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
-        const float dv = a[(j0 + r) * LDA + j0 + c];
-        v[c] = inv ? (c == r ? 1.f : 0.f) : dv;
+        d[c] = a[(j0 + r) * LDA + j0 + c];
+        x[c] = (c == r) ? 1.f : 0.f;
     }
-    int bad = 0;                                           // first non-positive / NaN pivot (wave-uniform), reported once below
+    int bad = 0;                                           // first non-positive / NaN pivot, reported once below
+    diag16_pivots<0>(d, x, r, bad);
+    diag16_report(bad, info, col0, lane);
+    if (lane < 16) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        float piv = rdlane(v[k], k);
-        const bool neg = !(piv > 0.f);
-        bad = (neg && bad == 0) ? k + 1 : bad;
-        piv = neg ? 1.f : piv;
-        float ri = __builtin_amdgcn_rsqf(piv);
-        ri = ri * (1.5f - 0.5f * piv * ri * ri);          // one Newton step: ~0.5 ulp
-        v[k] = (!inv && r == k) ? piv * ri : v[k] * ri;   // L[k][k] = sqrt(piv); column k of L; X[k][:] /= L[k][k]
-#pragma unroll
-        for (int c = k + 1; c < 16; ++c) {
-            const float l = rdlane(v[k], c);              // L[c][k]  (lane c of the factor half)
-            v[c] -= v[k] * l;
-        }
-    }
-    if (bad && lane == 0) {               // info[0]: this factorization; info[1], info[2]: sticky (first column, count)
-        atomicCAS(info, 0, col0 + bad);  //          until oisat_solve_status clears them
-        atomicCAS(info + 1, 0, col0 + bad);
-        atomicAdd(info + 2, 1);
-        atomicCAS(info + 3, 0, (int)blockIdx.x + 1);   // batched factorization: which matrix of the table (1-based)
-    }
-    if (lane < 16) {                      // L: lower part of row r (the upper part of the block now belongs to X^T)
-#pragma unroll
-        for (int c = 0; c < 16; ++c)
-            if (c <= r) a[(j0 + r) * LDA + j0 + c] = v[c];
-    } else if (lane < 32) {               // X[c][r], c > r, goes to its transposed place a[r][c]; X[r][r] to tdiag
-#pragma unroll
-        for (int c = 0; c < 16; ++c)
-            if (c > r) a[(j0 + r) * LDA + j0 + c] = v[c];
-        tdiag[j0 + r] = v[r];
+        for (int c = 0; c < 16; ++c) a[(j0 + r) * LDA + j0 + c] = (c <= r) ? d[c] : x[c];   // X[c][r], c > r, at a[r][c]
+        tdiag[j0 + r] = x[r];
     }
 }
 
@@ -879,10 +907,7 @@ constexpr int DINV_LD = 17;
 constexpr int DINV_SZ = 16 * DINV_LD;
 
 
-// Factor and invert in ONE sweep: column k of L is final after pivot step k, and that is exactly when the forward
-// substitution for X = L^-1 (lane = column r of X) needs it, so each broadcast L[c][k] = readlane(d[k], c) feeds both
-// the trailing update of the factor and the running sums of the inverse.  Half the serial broadcasts of doing the
-// two one after the other.
+// Two-image form: L to the a image (upper part of the block zeroed), X = L^-1 to dinvJ[16][17].
 __device__ __forceinline__ void diag16_factor_invert2(float* a, int j0, float* dinvJ, int* info, int col0, int lane) {
     const int r = lane & 15;
     float d[16], x[16];
@@ -891,30 +916,9 @@ __device__ __forceinline__ void diag16_factor_invert2(float* a, int j0, float* d
         d[c] = a[(j0 + r) * LDA + j0 + c];
         x[c] = (c == r) ? 1.f : 0.f;                       // running delta_{c,r} - sum_{k<c} L[c][k] X[k][r]
     }
-    int bad = 0;                                           // first non-positive / NaN pivot (wave-uniform), reported once below
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        float piv = rdlane(d[k], k);
-        const bool neg = !(piv > 0.f);
-        bad = (neg && bad == 0) ? k + 1 : bad;
-        piv = neg ? 1.f : piv;
-        float ri = __builtin_amdgcn_rsqf(piv);
-        ri = ri * (1.5f - 0.5f * piv * ri * ri);          // one Newton step: ~0.5 ulp
-        d[k] = (r == k) ? piv * ri : d[k] * ri;
-        x[k] = (k >= r) ? x[k] * ri : 0.f;
-#pragma unroll
-        for (int c = k + 1; c < 16; ++c) {
-            const float l = rdlane(d[k], c);              // L[c][k]
-            d[c] -= d[k] * l;
-            x[c] -= l * x[k];
-        }
-    }
-    if (bad && lane == 0) {               // info[0]: this factorization; info[1], info[2]: sticky (first column, count)
-        atomicCAS(info, 0, col0 + bad);
-        atomicCAS(info + 1, 0, col0 + bad);
-        atomicAdd(info + 2, 1);
-        atomicCAS(info + 3, 0, (int)blockIdx.x + 1);   // batched factorization: which matrix of the table (1-based)
-    }
+    int bad = 0;                                           // first non-positive / NaN pivot, reported once below
+    diag16_pivots<0>(d, x, r, bad);
+    diag16_report(bad, info, col0, lane);
 #pragma unroll
     for (int c = 0; c < 16; ++c)
         if (lane < 16) a[(j0 + r) * LDA + j0 + c] = (c <= r) ? d[c] : 0.f;
