@@ -927,7 +927,9 @@ __device__ __forceinline__ void diag16_factor_invert2(float* a, int j0, float* d
         if (lane < 16) dinvJ[rr * DINV_LD + r] = x[rr];
 }
 
-__global__ __launch_bounds__(256) void potrf_diag2_kernel(float* __restrict__ S, int64_t ld, int64_t k0, float* __restrict__ tinv,
+constexpr int kDiag2Threads = 512, kDiag2Waves = kDiag2Threads / 64, kDiag2Rows = NB * 32 / kDiag2Threads;   // rows per thread in the 128x128 copies
+
+__global__ __launch_bounds__(kDiag2Threads) void potrf_diag2_kernel(float* __restrict__ S, int64_t ld, int64_t k0, float* __restrict__ tinv,
                                                           int* __restrict__ info, int block_index, const BatchMat* __restrict__ mats) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     if (mats) {                            // batched: workgroup = matrix blockIdx.x of the table (largest first)
@@ -943,22 +945,23 @@ __global__ __launch_bounds__(256) void potrf_diag2_kernel(float* __restrict__ S,
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int lr = lane & 15, lg = lane >> 4;
     float* Sb = S + k0 * ld + k0;
-    {   // 16 independent 16-byte loads per thread, issued together (row = (tid>>5)+8p, 4 columns at (tid&31)*4).
+    {   // independent 16-byte loads, issued together (row = (tid>>5) + 16p, 4 columns at (tid&31)*4).
         // Row stride 130 floats keeps (r, c) with c % 4 == 0 8-byte aligned: two ds_write_b64 per quad.
         // (t needs no clearing: every element of it that is read later has been written by then.)
-        float4 v[16];
+        float4 v[kDiag2Rows];
 #pragma unroll
-        for (int p = 0; p < 16; ++p) v[p] = *reinterpret_cast<const float4*>(Sb + (int64_t)((tid >> 5) + 8 * p) * ld + (tid & 31) * 4);
+        for (int p = 0; p < kDiag2Rows; ++p)
+            v[p] = *reinterpret_cast<const float4*>(Sb + (int64_t)((tid >> 5) + (kDiag2Threads / 32) * p) * ld + (tid & 31) * 4);
 #pragma unroll
-        for (int p = 0; p < 16; ++p) {
-            const int r = (tid >> 5) + 8 * p, c = (tid & 31) * 4;
+        for (int p = 0; p < kDiag2Rows; ++p) {
+            const int r = (tid >> 5) + (kDiag2Threads / 32) * p, c = (tid & 31) * 4;
             float2* q = reinterpret_cast<float2*>(a + r * LDA + c);
             q[0] = make_float2((c + 0 <= r) ? v[p].x : 0.f, (c + 1 <= r) ? v[p].y : 0.f);
             q[1] = make_float2((c + 2 <= r) ? v[p].z : 0.f, (c + 3 <= r) ? v[p].w : 0.f);
         }
     }
     __syncthreads();
-    // Look-ahead: while waves 1-3 apply the trailing update of block column J, wave 0 updates only the next
+    // Look-ahead: while the other waves apply the trailing update of block column J, wave 0 updates only the next
     // diagonal block and immediately factors/inverts it, so the serial 16x16 factorizations (the longest
     // single-wave stretch) hide behind the MFMA updates instead of adding to them.
     if (w == 0) diag16_factor_invert2(a, 0, dinv, info, (int)k0, lane);
@@ -966,7 +969,7 @@ __global__ __launch_bounds__(256) void potrf_diag2_kernel(float* __restrict__ S,
     for (int J = 0; J < 8; ++J) {
         const int j0 = 16 * J;
         const float* dJ = dinv + J * DINV_SZ;
-        for (int I = J + 1 + w; I < 8; I += 4) {          // panel: P_I = A[I,J] * Dinv^T
+        for (int I = J + 1 + w; I < 8; I += kDiag2Waves) { // panel: P_I = A[I,J] * Dinv^T
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -980,7 +983,7 @@ __global__ __launch_bounds__(256) void potrf_diag2_kernel(float* __restrict__ S,
         __syncthreads();
         if (J == 7) break;
         const int n = 7 - J, np = n * (n + 1) / 2;        // trailing pairs (I >= K > J); pair 0 = (J+1, J+1)
-        const int pfirst = (w == 0) ? 0 : w, pstep = (w == 0) ? np : 3;          // wave 0: pair 0 only
+        const int pfirst = (w == 0) ? 0 : w, pstep = (w == 0) ? np : kDiag2Waves - 1;   // wave 0: pair 0 only
         for (int p = pfirst; p < np; p += pstep) {
             int kk = 0, rem = p;
             while (rem >= n - kk) { rem -= n - kk; ++kk; }
@@ -1001,7 +1004,7 @@ __global__ __launch_bounds__(256) void potrf_diag2_kernel(float* __restrict__ S,
         __syncthreads();
     }
     // ---- T = L^-1 -----------------------------------------------------------------------------
-    for (int idx = tid; idx < 8 * 256; idx += 256) {       // diagonal 16-blocks of T
+    for (int idx = tid; idx < 8 * 256; idx += kDiag2Threads) {   // diagonal 16-blocks of T
         const int J = idx >> 8, rr = (idx >> 4) & 15, cc = idx & 15;
         t[(16 * J + rr) * LDA + 16 * J + cc] = dinv[J * DINV_SZ + rr * DINV_LD + cc];
     }
@@ -1009,7 +1012,7 @@ __global__ __launch_bounds__(256) void potrf_diag2_kernel(float* __restrict__ S,
     for (int hb = 1; hb <= 4; hb *= 2) {                   // half size in 16-blocks
         const int h = 16 * hb, npairs = 8 / (2 * hb), nout = npairs * hb * hb;
         // phase A: X = L21 * T11  -> upper mirror of a
-        for (int o = w; o < nout; o += 4) {
+        for (int o = w; o < nout; o += kDiag2Waves) {
             const int pr = o / (hb * hb), bi = (o / hb) % hb, bj = o % hb;
             const int c0 = pr * 2 * h;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -1026,7 +1029,7 @@ __global__ __launch_bounds__(256) void potrf_diag2_kernel(float* __restrict__ S,
         }
         __syncthreads();
         // phase B: T21 = -T22 * X
-        for (int o = w; o < nout; o += 4) {
+        for (int o = w; o < nout; o += kDiag2Waves) {
             const int pr = o / (hb * hb), bi = (o / hb) % hb, bj = o % hb;
             const int c0 = pr * 2 * h;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -1045,11 +1048,11 @@ __global__ __launch_bounds__(256) void potrf_diag2_kernel(float* __restrict__ S,
     }
     float* Tg = tinv + (int64_t)block_index * NB * NB;
 #pragma unroll
-    for (int hp = 0; hp < 2; ++hp) {       // LDS reads of 8 rows first (ds_read_b64), then their stores
+    for (int hp = 0; hp < kDiag2Rows / 8; ++hp) {   // LDS reads of 8 rows first (ds_read_b64), then their stores
         float2 ql[8][2], zl[8][2];
 #pragma unroll
         for (int pp = 0; pp < 8; ++pp) {
-            const int r = (tid >> 5) + 8 * (hp * 8 + pp), c = (tid & 31) * 4;
+            const int r = (tid >> 5) + (kDiag2Threads / 32) * (hp * 8 + pp), c = (tid & 31) * 4;
             const float2* q = reinterpret_cast<const float2*>(a + r * LDA + c);
             const float2* z = reinterpret_cast<const float2*>(t + r * LDA + c);
             ql[pp][0] = q[0]; ql[pp][1] = q[1];
@@ -1057,7 +1060,7 @@ __global__ __launch_bounds__(256) void potrf_diag2_kernel(float* __restrict__ S,
         }
 #pragma unroll
         for (int pp = 0; pp < 8; ++pp) {
-            const int r = (tid >> 5) + 8 * (hp * 8 + pp), c = (tid & 31) * 4;
+            const int r = (tid >> 5) + (kDiag2Threads / 32) * (hp * 8 + pp), c = (tid & 31) * 4;
             float* g = Sb + (int64_t)r * ld + c;
             if (c + 3 <= r) *reinterpret_cast<float4*>(g) = make_float4(ql[pp][0].x, ql[pp][0].y, ql[pp][1].x, ql[pp][1].y);
             else {
@@ -1409,7 +1412,7 @@ int potrf_rec_batched(oisat_ctx* h, const ChBatch& bt, int b0, int b1, int* info
             OISAT_LAUNCH(h, "potrf_diag", potrf_diag_kernel, dim3((unsigned)cnt), dim3(256), kDiagShm, (float*)nullptr, (int64_t)0,
                          (int64_t)b0 * NB, (float*)nullptr, info_dev, b0, (const BatchMat*)bt.table_dev);
         } else {
-            OISAT_LAUNCH(h, "potrf_diag", potrf_diag2_kernel, dim3((unsigned)cnt), dim3(256), kDiag2Shm, (float*)nullptr, (int64_t)0,
+            OISAT_LAUNCH(h, "potrf_diag", potrf_diag2_kernel, dim3((unsigned)cnt), dim3(kDiag2Threads), kDiag2Shm, (float*)nullptr, (int64_t)0,
                          (int64_t)b0 * NB, (float*)nullptr, info_dev, b0, (const BatchMat*)bt.table_dev);
         }
         return launch_gemm_batched(h, "trsm_gemm", bt, BatchArgs{bt.table_dev, 1, b0, 0, 0}, NB, 1, 0);
@@ -1441,7 +1444,7 @@ int potrf_rec(oisat_ctx* h, float* S, int64_t ld, int64_t mpb, int64_t b0, int64
             OISAT_LAUNCH(h, "potrf_diag", potrf_diag_kernel, dim3(1), dim3(256), kDiagShm, S, ld, k0, tinv, info_dev, (int)b0,
                          (const BatchMat*)nullptr);
         } else {
-            OISAT_LAUNCH(h, "potrf_diag", potrf_diag2_kernel, dim3(1), dim3(256), kDiag2Shm, S, ld, k0, tinv, info_dev, (int)b0,
+            OISAT_LAUNCH(h, "potrf_diag", potrf_diag2_kernel, dim3(1), dim3(kDiag2Threads), kDiag2Shm, S, ld, k0, tinv, info_dev, (int)b0,
                          (const BatchMat*)nullptr);
         }
         const int64_t rows = (mpb - b0 - 1) * NB;
