@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--no-config4", action="store_true", help="skip the fixed-workload strong-scaling leg (12 months x tiles)")
     ap.add_argument("--c4-months", type=int, default=12)
     ap.add_argument("--c4-passes", type=int, default=2)
+    ap.add_argument("--c4-shards", default="", help="e.g. 1,2,4,8: emulate the config-4 strong-scaling curve on ONE GPU by timing "
+                    "every rank's shard of each world size alone (prints only that leg)")
     ap.add_argument("--backend", default="nccl", help="process-group backend; gloo only to rehearse N>1 on a 1-GPU box")
     ap.add_argument("--rehearse-on-device0", action="store_true", help="every rank uses GPU 0 (rehearsal only)")
     return ap.parse_args()
@@ -437,6 +439,80 @@ def cpu_baseline(workload):
     out["regrid_type4_s_for_3_fields"] = time.perf_counter() - t1
     return out
 
+def _c4_workload(args, lat2, lon2):
+    """The fixed config-4 workload: (month x tile) units with their obs^3 weights and cell counts (seeded: every rank
+    derives the same months, nothing to broadcast)."""
+    from oisatgmi import synthetic as syn, dense
+    ny, nx, nobs, L, swaths, refine = WORKLOADS[DEFAULT]
+    halo = 3.0 * L
+    cases, units, weights, cells = {}, [], [], []
+    for mth in range(args.c4_months):
+        p = syn.point_obs_case(ny, nx, nobs, 4000 + mth, swaths=swaths)
+        cases[mth] = p
+        for ti, t in enumerate(dense.tile_partition(lat2, lon2, p.obs_lat, p.obs_lon, 30.0, halo)):
+            if t["obs"].size:
+                units.append((mth, ti))
+                weights.append(float(t["obs"].size) ** 3)
+                cells.append((t["rows"][1] - t["rows"][0]) * (t["cols"][1] - t["cols"][0]))
+    return cases, units, weights, cells
+
+
+def _c4_shard(ctx, args, cases, units, part, lat2, lon2, cap):
+    """One rank's shard of the config-4 units as a MonthTileBatch on the lanes of one pool."""
+    from oisatgmi import dense
+    halo = 3.0 * WORKLOADS[DEFAULT][3]
+    batch = dense.MonthTileBatch(lat2, lon2, 30.0, halo, np.float32, ctx=ctx, streams=12)
+    for mth in range(args.c4_months):
+        only = [units[i][1] for i in part if units[i][0] == mth]
+        if only:
+            p = cases[mth]
+            batch.add_month(mth, p.Xa, p.Sa, p.obs_lat, p.obs_lon, p.obs_y, p.obs_var, only=only)
+    batch.build(min_slab_elems=cap)
+    assert sorted((k, ti) for k, ti, _ in batch.units) == sorted(units[i] for i in part)
+    return batch
+
+
+def config4_shards_leg(ctx, args, lat2, lon2, sync, worlds):
+    """Single-GPU EMULATION of the strong-scaling curve of config 4: for every world size W in `worlds` the W shards of
+    the same obs^3-weighted LPT partition the multi-GPU leg uses are run ONE AFTER THE OTHER on this GPU, each exactly as
+    its rank would run it (own MonthTileBatch, own lanes, whole shard enqueued, checked at the end), and timed alone.
+    max_r seconds(W, r) is what the slowest rank of a W-GPU job would need before the gather (one dist.gather of a few
+    tens of MB per rank over xGMI, not emulated here); seconds(1) / max_r seconds(W, r) is the speed-up that W GPUs of
+    this kind would give.  It measures what a load-balance bound cannot: the fixed per-rank costs (polar caps, lock-step
+    levels with few members, host enqueue) that do not shrink with the shard."""
+    from oisatgmi import parallel
+    _, _, _, L, _, refine = WORKLOADS[DEFAULT]
+    cases, units, weights, cells = _c4_workload(args, lat2, lon2)
+    out = {"workload": f"{args.c4_months} months x (720x1440, 1e5 swath obs) as {len(units)} (month x tile) units",
+           "note": "single-GPU emulation: the W shards of a W-rank job timed one after the other on one MI355X; no gather"}
+    base = None
+    for W in worlds:
+        parts = parallel.partition_units(len(units), W, weights)
+        secs = []
+        for r in range(W):
+            cap = sum(2 * cells[i] for i in parts[r])
+            batch = _c4_shard(ctx, args, cases, units, parts[r], lat2, lon2, cap)
+            batch.run(L, refine=refine, check_pd=True)
+            batch.run(L, refine=refine, wait=False)
+            batch.check()
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(args.c4_passes):
+                batch.run(L, refine=refine, wait=False)
+                batch.check()
+            sync()
+            secs.append((time.perf_counter() - t0) / args.c4_passes)
+            batch.close()
+        if W == 1:
+            base = secs[0]
+        loads = [sum(weights[i] for i in part) for part in parts]
+        out[f"world_{W}"] = {"rank_seconds": [round(x, 4) for x in secs], "slowest_rank_seconds": max(secs),
+                             "speedup_vs_1": (base / max(secs)) if base else None,
+                             "speedup_bound_from_load_balance": sum(loads) / max(loads),
+                             "units_per_rank": [len(part) for part in parts]}
+    return out
+
+
 def config4_leg(ctx, args, world, rank, local, lat2, lon2, sync, barrier):
     """BASELINE configs[3], STRONG scaling: a FIXED workload -- `c4_months` synthetic 720x1440 months of 10^5 swath
     observations, each cut into 30 deg x 30 deg tiles with a 3 L halo (localised block-B) -- split into (month x tile)
@@ -447,29 +523,14 @@ def config4_leg(ctx, args, world, rank, local, lat2, lon2, sync, barrier):
     only unit 8 GPUs cap at 12/2 = 6.0x, hence the finer unit)."""
     import torch
     import torch.distributed as dist
-    from oisatgmi import synthetic as syn, dense, parallel
+    from oisatgmi import dense, parallel
     ny, nx, nobs, L, swaths, refine = WORKLOADS[DEFAULT]
     halo = 3.0 * L
-    cases, units, weights, cells = {}, [], [], []
-    for mth in range(args.c4_months):                     # seeded: every rank derives the same months, nothing to broadcast
-        p = syn.point_obs_case(ny, nx, nobs, 4000 + mth, swaths=swaths)
-        cases[mth] = p
-        for ti, t in enumerate(dense.tile_partition(lat2, lon2, p.obs_lat, p.obs_lon, 30.0, halo)):
-            if t["obs"].size:
-                units.append((mth, ti))
-                weights.append(float(t["obs"].size) ** 3)
-                cells.append((t["rows"][1] - t["rows"][0]) * (t["cols"][1] - t["cols"][0]))
+    cases, units, weights, cells = _c4_workload(args, lat2, lon2)
     parts = parallel.partition_units(len(units), world, weights)
     loads = [sum(weights[i] for i in part) for part in parts]
     cap = max(sum(2 * cells[i] for i in part) for part in parts)      # slab elements every rank sends
-    batch = dense.MonthTileBatch(lat2, lon2, 30.0, halo, np.float32, ctx=ctx, streams=12)
-    for mth in range(args.c4_months):
-        only = [units[i][1] for i in parts[rank] if units[i][0] == mth]
-        if only:
-            p = cases[mth]
-            batch.add_month(mth, p.Xa, p.Sa, p.obs_lat, p.obs_lon, p.obs_y, p.obs_var, only=only)
-    batch.build(min_slab_elems=cap)
-    assert sorted((k, ti) for k, ti, _ in batch.units) == sorted(units[i] for i in parts[rank])
+    batch = _c4_shard(ctx, args, cases, units, parts[rank], lat2, lon2, cap)
     del cases
     send = torch.as_tensor(parallel._DevView(batch.slab.ptr, cap, "<f4"), device=torch.device("cuda", local))
 
@@ -564,6 +625,12 @@ def main():
         return
     # ---- shared grid: built on rank 0, broadcast once (RCCL) -------------------------------------
     lat2, lon2 = syn.global_grid(ny, nx)
+    if args.c4_shards:
+        if world != 1:
+            raise SystemExit("--c4-shards is a single-GPU emulation")
+        worlds = sorted({1} | {int(w) for w in args.c4_shards.split(",")})
+        print(json.dumps({"config4_shards_emulated": config4_shards_leg(ctx, args, lat2, lon2, sync, worlds)}))
+        return
     if world > 1:
         lat2, lon2 = parallel.broadcast_grid(lat2 if rank == 0 else None, lon2 if rank == 0 else None, (ny, nx), local)
     # ---- this rank's month ------------------------------------------------------------------------

@@ -1315,7 +1315,8 @@ static const int kBigK = getenv("OISAT_GEMM_BIG_K") ? atoi(getenv("OISAT_GEMM_BI
 // (a multiple of 8, so that workgroup b keeps its XCD for all of its tiles)
 static inline unsigned persistent_grid(const oisat_ctx* h, int64_t virtual_tiles) {
     static const int per_cu = getenv("OISAT_GEMM_WG_PER_CU") ? atoi(getenv("OISAT_GEMM_WG_PER_CU")) : 2;
-    const int64_t slots = ((int64_t)(h->cu_count > 0 ? h->cu_count : 256) * per_cu) / 8 * 8;
+    static const int spare = getenv("OISAT_GEMM_SPARE_SLOTS") ? atoi(getenv("OISAT_GEMM_SPARE_SLOTS")) : 0;
+    const int64_t slots = ((int64_t)(h->cu_count > 0 ? h->cu_count : 256) * per_cu - spare) / 8 * 8;
     return (unsigned)(virtual_tiles <= slots || per_cu <= 0 ? virtual_tiles : slots);
 }
 

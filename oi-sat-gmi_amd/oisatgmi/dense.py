@@ -280,10 +280,11 @@ def tile_partition(lat2, lon2, obs_lat, obs_lon, tile_deg=30.0, halo_km=900.0, m
 class BatchedFactor:
     """Lock-step factorization of many plans (``oisat_batch_potrf``): the plans are sorted by size and cut into groups of
     comparable block count (a group's smallest matrix has at least ``ratio`` of the blocks of its largest) -- in a
-    720x1440 month: the 48 mid-latitude tiles (31-48 blocks) and the two polar caps (137 blocks).  The groups are
-    groups run side by side, one stream each (``OISAT_BATCH_SCHEDULE`` selects two other schedules that measured the same)."""
+    720x1440 month: the 48 mid-latitude tiles (31-48 blocks) and the two polar caps (137 blocks).  The groups run side
+    by side, one stream each, and each group's solves start when it is factored (``OISAT_BATCH_SCHEDULE``)."""
 
     def __init__(self, device: int, plans, ratio: float = 0.5):
+        ratio = float(os.environ.get("OISAT_BATCH_RATIO", ratio))
         groups = []
         order = sorted((p for p in plans if p is not None), key=lambda p: -p.m)
         cur = []
@@ -295,11 +296,16 @@ class BatchedFactor:
         if cur:
             groups.append(cur)
         self.groups = groups[::-1]                          # smallest systems first
-        # schedule (OISAT_BATCH_SCHEDULE): "concurrent" -- one stream per group, all groups at once, then the solves;
-        # "serial" -- one stream, group after group, then the solves; "interleave" -- one stream, and the lanes start a
-        # group's solves as soon as it is factored, underneath the next group's GEMMs
-        self.schedule = os.environ.get("OISAT_BATCH_SCHEDULE", "concurrent")
+        # schedule (OISAT_BATCH_SCHEDULE): "overlap" (default) -- one stream per group, all groups at once, and the lanes
+        # start a group's solves as soon as THAT group is factored (the mid-latitude tiles' triangular solves and
+        # increments run underneath the polar caps' factorization); "concurrent" -- the same, but all solves wait for
+        # all groups; "serial" -- one group after the other, then the solves; "interleave" -- serial groups, each
+        # group's solves underneath the next group's GEMMs
+        self.schedule = os.environ.get("OISAT_BATCH_SCHEDULE", "overlap")
         self.ctxs = [_hip.Context(device).own_stream() for _ in self.groups]
+        if os.environ.get("OISAT_BATCH_DIAG_SMALL", "0") == "1":
+            for c in self.ctxs:
+                c.check(c.lib.oisat_diag_lds(c.h, 1))
         self.ids = []
         for g, ctx in zip(self.groups, self.ctxs):
             n = len(g)
@@ -312,7 +318,8 @@ class BatchedFactor:
             self.ids.append(bid.value)
         self.group_of = {id(p): gi for gi, g in enumerate(self.groups) for p in g}
         # measured (ms per run: 1 month / 4 months / 12 months of 720x1440, 1e5 obs): concurrent 92 / 281 / 761,
-        # serial 106 / 299 / 783, interleave 87 / 296 / 791 -- within noise of each other; concurrent is the default
+        # serial 106 / 299 / 783, interleave 87 / 296 / 791; overlap against concurrent on one box: 12 months 750 vs 769,
+        # one eighth of them (a rank's shard of an 8-GPU job: 3 caps + 72 tiles) 124.5 vs 135
 
     def run(self, pool, per_lane_plans, refine, check_pd=False):
         """``per_lane_plans[li]``: the plans of lane li in run order, already BUILT (their S enqueued on the lane)."""
@@ -321,7 +328,7 @@ class BatchedFactor:
             lanes = list({id(p.ctx): p.ctx for p in g}.values())
             for lane in lanes:
                 ctx.wait_for(lane)
-            if prev is not None and self.schedule != "concurrent":
+            if prev is not None and self.schedule not in ("concurrent", "overlap"):
                 ctx.wait_for(prev)                          # group after group
             info = (C.c_int * 2)(0, -1)
             ctx.check(ctx.lib.oisat_batch_potrf(ctx.h, bid, info if check_pd else None))
@@ -331,7 +338,13 @@ class BatchedFactor:
                     lane.wait_for(ctx)
                 pool.enqueue([[(lambda p=p: p.run_solve(refine)) for p in plans if self.group_of[id(p)] == gi]
                               for plans in per_lane_plans])
-        if self.schedule != "interleave":
+        if self.schedule == "overlap":                      # all groups are in flight: a group's solves wait for it alone
+            for gi, (g, ctx) in enumerate(zip(self.groups, self.ctxs)):
+                for lane in {id(p.ctx): p.ctx for p in g}.values():
+                    lane.wait_for(ctx)
+                pool.enqueue([[(lambda p=p: p.run_solve(refine)) for p in plans if self.group_of[id(p)] == gi]
+                              for plans in per_lane_plans])
+        elif self.schedule != "interleave":
             for lane in pool.lanes:
                 for ctx in self.ctxs:
                     lane.wait_for(ctx)
