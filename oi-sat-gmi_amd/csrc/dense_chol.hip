@@ -28,6 +28,7 @@
 // a diagonal block is then a GEMM with the inverse (TRSM as GEMM, the MAGMA trick), so it also
 // runs on MFMA.  The inverses are kept: the triangular solves reuse them.
 #include "oisat_common.h"
+#include <cstring>
 
 #include <algorithm>
 
@@ -1315,8 +1316,7 @@ static const int kBigK = getenv("OISAT_GEMM_BIG_K") ? atoi(getenv("OISAT_GEMM_BI
 // (a multiple of 8, so that workgroup b keeps its XCD for all of its tiles)
 static inline unsigned persistent_grid(const oisat_ctx* h, int64_t virtual_tiles) {
     static const int per_cu = getenv("OISAT_GEMM_WG_PER_CU") ? atoi(getenv("OISAT_GEMM_WG_PER_CU")) : 2;
-    static const int spare = getenv("OISAT_GEMM_SPARE_SLOTS") ? atoi(getenv("OISAT_GEMM_SPARE_SLOTS")) : 0;
-    const int64_t slots = ((int64_t)(h->cu_count > 0 ? h->cu_count : 256) * per_cu - spare) / 8 * 8;
+    const int64_t slots = ((int64_t)(h->cu_count > 0 ? h->cu_count : 256) * per_cu) / 8 * 8;
     return (unsigned)(virtual_tiles <= slots || per_cu <= 0 ? virtual_tiles : slots);
 }
 
@@ -1418,7 +1418,10 @@ int potrf_rec_batched(oisat_ctx* h, const ChBatch& bt, int b0, int b1, int* info
         }
         return launch_gemm_batched(h, "trsm_gemm", bt, BatchArgs{bt.table_dev, 1, b0, 0, 0}, NB, 1, 0);
     }
-    const int mid = b0 + (b1 - b0 + 1) / 2;
+    static const bool pow2 = getenv("OISAT_BATCH_TREE") && !strcmp(getenv("OISAT_BATCH_TREE"), "pow2");
+    int half = 1;
+    while (2 * half < b1 - b0) half *= 2;                  // largest power of two strictly below the node's size
+    const int mid = pow2 ? b0 + half : b0 + (b1 - b0 + 1) / 2;
     int rc = potrf_rec_batched(h, bt, b0, mid, info_dev);
     if (rc) return rc;
     rc = launch_gemm_batched(h, "syrk_gemm", bt, BatchArgs{bt.table_dev, 0, b0, mid, b1}, (mid - b0) * NB, 0, 1);

@@ -284,7 +284,6 @@ class BatchedFactor:
     by side, one stream each, and each group's solves start when it is factored (``OISAT_BATCH_SCHEDULE``)."""
 
     def __init__(self, device: int, plans, ratio: float = 0.5):
-        ratio = float(os.environ.get("OISAT_BATCH_RATIO", ratio))
         groups = []
         order = sorted((p for p in plans if p is not None), key=lambda p: -p.m)
         cur = []
@@ -303,9 +302,6 @@ class BatchedFactor:
         # group's solves underneath the next group's GEMMs
         self.schedule = os.environ.get("OISAT_BATCH_SCHEDULE", "overlap")
         self.ctxs = [_hip.Context(device).own_stream() for _ in self.groups]
-        if os.environ.get("OISAT_BATCH_DIAG_SMALL", "0") == "1":
-            for c in self.ctxs:
-                c.check(c.lib.oisat_diag_lds(c.h, 1))
         self.ids = []
         for g, ctx in zip(self.groups, self.ctxs):
             n = len(g)
@@ -339,9 +335,18 @@ class BatchedFactor:
                 pool.enqueue([[(lambda p=p: p.run_solve(refine)) for p in plans if self.group_of[id(p)] == gi]
                               for plans in per_lane_plans])
         if self.schedule == "overlap":                      # all groups are in flight: a group's solves wait for it alone
+            # The HOST waits for the group (smallest systems first: they finish first), then enqueues its solves.  A
+            # device-side wait (lane.wait_for) would park a barrier packet at the head of every lane's hardware queue
+            # for the whole factorization, and the command processor polls parked queues at the expense of the running
+            # one: with 12 parked lanes every kernel of the dependent chain took 40-60 us longer (potrf_diag 27 -> 64,
+            # the panel TRSM 17 -> 80 us in the rocprofv3 trace), a third of a polar cap's factorization time.
+            device_wait = os.environ.get("OISAT_BATCH_DEVICE_WAIT", "0") == "1"
             for gi, (g, ctx) in enumerate(zip(self.groups, self.ctxs)):
-                for lane in {id(p.ctx): p.ctx for p in g}.values():
-                    lane.wait_for(ctx)
+                if device_wait:
+                    for lane in {id(p.ctx): p.ctx for p in g}.values():
+                        lane.wait_for(ctx)
+                else:
+                    ctx.sync()
                 pool.enqueue([[(lambda p=p: p.run_solve(refine)) for p in plans if self.group_of[id(p)] == gi]
                               for plans in per_lane_plans])
         elif self.schedule != "interleave":
