@@ -295,11 +295,10 @@ class BatchedFactor:
         if cur:
             groups.append(cur)
         self.groups = groups[::-1]                          # smallest systems first
-        # schedule (OISAT_BATCH_SCHEDULE): "overlap" (default) -- one stream per group, all groups at once, and the lanes
-        # start a group's solves as soon as THAT group is factored (the mid-latitude tiles' triangular solves and
-        # increments run underneath the polar caps' factorization); "concurrent" -- the same, but all solves wait for
-        # all groups; "serial" -- one group after the other, then the solves; "interleave" -- serial groups, each
-        # group's solves underneath the next group's GEMMs
+        # schedule (OISAT_BATCH_SCHEDULE): "overlap" (default) -- one stream per group, all groups side by side;
+        # "sequential" -- the groups one after the other (each one's dependent chain then runs at its isolated speed and
+        # its solves go underneath the next group's factorization).  Either way a group's solves start when THAT group
+        # is factored.
         self.schedule = os.environ.get("OISAT_BATCH_SCHEDULE", "overlap")
         self.ctxs = [_hip.Context(device).own_stream() for _ in self.groups]
         self.ids = []
@@ -313,47 +312,32 @@ class BatchedFactor:
             ctx.check(ctx.lib.oisat_batch_create(ctx.h, n, Sp, mm, ld, Tp, C.byref(bid)))
             self.ids.append(bid.value)
         self.group_of = {id(p): gi for gi, g in enumerate(self.groups) for p in g}
-        # measured (ms per run: 1 month / 4 months / 12 months of 720x1440, 1e5 obs): concurrent 92 / 281 / 761,
-        # serial 106 / 299 / 783, interleave 87 / 296 / 791; overlap against concurrent on one box: 12 months 750 vs 769,
-        # one eighth of them (a rank's shard of an 8-GPU job: 3 caps + 72 tiles) 124.5 vs 135
+        # measured, one box (1 month of 720x1440 / 1e5 obs; a rank's eighth of 12 months; all 12 months):
+        # overlap 73.6 / 112 / 745 ms, sequential 77.0 / 119 / 746 ms
 
     def run(self, pool, per_lane_plans, refine, check_pd=False):
-        """``per_lane_plans[li]``: the plans of lane li in run order, already BUILT (their S enqueued on the lane)."""
+        """``per_lane_plans[li]``: the plans of lane li in run order, already BUILT (their S enqueued on the lane).
+
+        Every group's factorization is enqueued at once; the HOST then waits group by group (smallest systems first)
+        and enqueues that group's solves on the lanes -- it returns when the last group is factored and its solves
+        are enqueued.  (A device-side wait would park a barrier packet at the head of every lane's hardware queue for
+        the whole factorization, and the command processor polls parked queues at the expense of the running one:
+        with 12 parked lanes every kernel of the dependent chain took 40-60 us longer in the rocprofv3 trace --
+        potrf_diag 27 -> 64, the panel TRSM 17 -> 80 us -- a third of a polar cap's factorization time.)"""
+        sequential = self.schedule == "sequential"
         prev = None
         for gi, (g, ctx, bid) in enumerate(zip(self.groups, self.ctxs, self.ids)):
-            lanes = list({id(p.ctx): p.ctx for p in g}.values())
-            for lane in lanes:
-                ctx.wait_for(lane)
-            if prev is not None and self.schedule not in ("concurrent", "overlap"):
-                ctx.wait_for(prev)                          # group after group
+            for lane in {id(p.ctx): p.ctx for p in g}.values():
+                ctx.wait_for(lane)                          # short: the builds are a few ms
+            if sequential and prev is not None:
+                ctx.wait_for(prev)                          # one parked queue
             info = (C.c_int * 2)(0, -1)
             ctx.check(ctx.lib.oisat_batch_potrf(ctx.h, bid, info if check_pd else None))
             prev = ctx
-            if self.schedule == "interleave":
-                for lane in lanes:
-                    lane.wait_for(ctx)
-                pool.enqueue([[(lambda p=p: p.run_solve(refine)) for p in plans if self.group_of[id(p)] == gi]
-                              for plans in per_lane_plans])
-        if self.schedule == "overlap":                      # all groups are in flight: a group's solves wait for it alone
-            # The HOST waits for the group (smallest systems first: they finish first), then enqueues its solves.  A
-            # device-side wait (lane.wait_for) would park a barrier packet at the head of every lane's hardware queue
-            # for the whole factorization, and the command processor polls parked queues at the expense of the running
-            # one: with 12 parked lanes every kernel of the dependent chain took 40-60 us longer (potrf_diag 27 -> 64,
-            # the panel TRSM 17 -> 80 us in the rocprofv3 trace), a third of a polar cap's factorization time.
-            device_wait = os.environ.get("OISAT_BATCH_DEVICE_WAIT", "0") == "1"
-            for gi, (g, ctx) in enumerate(zip(self.groups, self.ctxs)):
-                if device_wait:
-                    for lane in {id(p.ctx): p.ctx for p in g}.values():
-                        lane.wait_for(ctx)
-                else:
-                    ctx.sync()
-                pool.enqueue([[(lambda p=p: p.run_solve(refine)) for p in plans if self.group_of[id(p)] == gi]
-                              for plans in per_lane_plans])
-        elif self.schedule != "interleave":
-            for lane in pool.lanes:
-                for ctx in self.ctxs:
-                    lane.wait_for(ctx)
-            pool.enqueue([[(lambda p=p: p.run_solve(refine)) for p in plans] for plans in per_lane_plans])
+        for gi, ctx in enumerate(self.ctxs):
+            ctx.sync()
+            pool.enqueue([[(lambda p=p: p.run_solve(refine)) for p in plans if self.group_of[id(p)] == gi]
+                          for plans in per_lane_plans])
 
     def check(self, what="batched factorization"):
         errors = []
