@@ -256,13 +256,6 @@ int oisat_gemm_nt(oisat_ctx* h, float* C, int64_t ldc, const float* A, int64_t l
  * trailing updates.  info_host: 0 ok, j>0 = first non-positive pivot column (1-based). */
 int oisat_potrf(oisat_ctx* h, float* S, int64_t m, int64_t ld, int* info_host);
 
-/* Which diagonal-block kernel oisat_potrf uses on this handle.  small = 0 (default): L and L^-1 in two LDS images, 137 KB --
- * the faster kernel (33 vs 43 us per 128 columns) but its workgroup needs a CU to itself; small != 0: one image, 67 KB
- * (T kept transposed in the free upper triangle), which fits on a CU next to a 64 KB gemm workgroup -- for handles whose
- * factorizations run CONCURRENTLY with other handles' (lane-parallel tiles), where the 137 KB kernel sits in the queue
- * until some CU has drained completely. */
-int oisat_diag_lds(oisat_ctx* h, int small);
-
 /* z <- L^-T L^-1 z  (dev double[m], fp32 factor, double accumulation). */
 int oisat_potrs(oisat_ctx* h, const float* L, int64_t m, int64_t ld, double* z_inout);
 

@@ -611,26 +611,7 @@ __global__ __launch_bounds__(256) void gemm_nt_rows64_kernel(float* C, int64_t l
     }
 }
 
-// ---- diagonal block: Cholesky + inverse of one 128x128 block, one workgroup, ONE LDS image ------
-// Right-looking at 16-column granularity, 4 waves.  Per block column J:
-//   (1) wave 0 factors the 16x16 diagonal block in registers (lane = row, columns in VGPRs, pivots
-//       broadcast with v_readlane) and inverts it in the same sweep;
-//   (2) panel below:   P_I  = A[I,J] * Dinv_J^T          (v_mfma_f32_16x16x4_f32, 4 per 16x16 block)
-//   (3) trailing:      A[I,K] -= P_I * P_K^T,  J < K <= I
-// then T = L^-1 by doubling (16 -> 32 -> 64 -> 128):  T21 = -T22 * (L21 * T11), both products on MFMA.
-//
-// LDS: a[128][130] floats and tdiag[128] -- 67,072 B, so the workgroup fits on a CU next to a 64 KB gemm_nt
-// workgroup (160 KB per CU).  Round 1 kept L and T in two images (137 KB): the kernel then needed an EMPTY CU, and in
-// any schedule that overlaps the diagonal chain with bulk updates it sat in the queue until a bulk launch drained
-// (300-350 us instead of 33).  Here the strictly upper triangle of the image -- free, L is lower -- holds T TRANSPOSED
-// (T[r][c], r > c, lives at a[c][r]) and tdiag holds T's diagonal; the inverse of each 16x16 diagonal block is written
-// straight to its final place by the wave that factors it.  The doubling step parks X = L21*T11 in the upper block
-// that T21^T will occupy: the T21 tiles are therefore held in registers across a barrier before they are written.
-// Row stride 130 floats: rows are 8-byte aligned, and 130 = 2 mod 32 spreads the (row = lane&15, k = lane>>4) MFMA
-// operand reads over the banks.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int LDA = 130;
-constexpr size_t kDiagShm = sizeof(float) * (NB * LDA + NB);
 
 // Factor and invert a 16x16 diagonal block in ONE sweep, in registers.  Lane r of every 16-lane row holds row r of the
 // block (d[c] = A[r][c]) and column r of the running inverse (x[c] = X[c][r], X = L^-1, starts as I): after pivot step k
@@ -693,36 +674,167 @@ __device__ __forceinline__ void diag16_report(int bad, int* info, int col0, int 
     }
 }
 
-// element (k, j) of a lower-triangular inverse block whose strictly-lower part is stored transposed above the diagonal of
-// the image (origin o on the diagonal) and whose diagonal is in tdiag:  k > j: a[o+j][o+k];  k == j: tdiag;  k < j: 0
-__device__ __forceinline__ float tri_t(const float* a, const float* tdiag, int o, int k, int j) {
-    const float off = a[(o + (k > j ? j : k)) * LDA + o + (k > j ? k : j)];          // always an upper (or diagonal) address
-    return k > j ? off : (k == j ? tdiag[o + j] : 0.f);
+// ---- diagonal block, REGISTER-RESIDENT: Cholesky + inverse of one 128x128 block, one workgroup of 4 waves, 20 KB of LDS ------
+// The 36 lower 16x16 tiles of the block live in MFMA accumulator registers for the whole kernel: the 8 diagonal tiles in
+// wave 0 (which also runs the serial 16x16 factorizations), off-diagonal tile (I, K), idx = I(I-1)/2 + K, in wave
+// 1 + idx % 3, slot idx / 3 (10 / 9 / 9 tiles).  A slot's accumulator holds A[I,K] until its panel step K makes it the
+// final L[I,K]; from then on the SAME register accumulates the running inverse X[I,K] until step I finishes it.  The
+// A phase holds the tile TRANSPOSED (lane: A[lr][4 lg + e], one float4 of a row): the trailing update just swaps its two
+// operands, and the panel product P_I^T = Dinv_J * A[I,J]^T then takes the held tile straight from the registers as the
+// MFMA's B operand (d3_mma_regb) -- as does X[J,K] = Dinv_J * accX[J,K] -- so the workers never stage a tile.  Every
+// tile coordinate is a compile-time constant of the wave's code path (one instantiation per wave), so each wave
+// executes straight-line code with exactly its own tile operations.  LDS only
+// carries what other waves need as MFMA operands: the current panel column P (= final L[:, J]), row J of X = L^-1, the
+// inverse of the current diagonal 16x16 block, and one staging tile for the 16x16 factorization (accumulator layout ->
+// lane = row).  Right-looking at 16-column granularity, per block column J:
+//   (1) the wave that owns tile (J, J) factors and inverts it in registers (diag16_pivots: lane = row);
+//   (2) panel:      P_I = A[I,J] * Dinv_J^T  (I > J)           row J of X:  X[J,K] = Dinv_J * accX[J,K]  (K < J)
+//   (3) trailing:   A[I,K] -= P_I * P_K^T  (I >= K > J)        inverse:     accX[I,K] -= P_I * X[J,K]    (I > J >= K)
+// i.e. the forward substitution for X = L^-1 rides along with the factorization (row J of X is final as soon as Dinv_J
+// is) instead of a separate doubling phase, the trailing updates never move an accumulator through LDS, and the owner
+// of (J+1, J+1) updates that tile first and factors it while the other waves finish step J (look-ahead).
+typedef __attribute__((address_space(1))) float gfloat;          // global address space: global_load / global_store, which the
+typedef __attribute__((address_space(1))) f32x4 gf32x4;         // LDS-only barrier does not wait for (flat_* count on lgkmcnt too)
+constexpr int D3_WAVES = 4, D3_THREADS = 64 * D3_WAVES, D3_LD = 17, D3_TILE = 16 * D3_LD;
+
+constexpr int d3_I(int idx) {              // idx = I(I-1)/2 + K, 0 <= K < I < 8
+    int I = 1;
+    while (I * (I + 1) / 2 <= idx) ++I;
+    return I;
+}
+constexpr int d3_K(int idx) { return idx - d3_I(idx) * (d3_I(idx) - 1) / 2; }
+
+// acc (rows 4*lg + e, column lr) += sum_k (+-a[lr][k]) * B[k][lr-th column]: 4 MFMAs over k = 4s + lg
+// A operand: element [lr][4s + lg] of a row-major 16 x D3_LD tile (negated if NEG); B operand either
+//   BT = true:  B[k][col] = bt[col][k]  -> element [lr][4s + lg] of bt           (C -= A * B^T form)
+//   BT = false: B[k][col] = b[k][col]   -> element [4s + lg][lr] of b
+template <bool NEG, bool BT>
+__device__ __forceinline__ f32x4 d3_mma(f32x4 acc, const float* a, const float* b, int lr, int lg) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const float av = a[lr * D3_LD + 4 * s + lg];
+        const float bv = BT ? b[lr * D3_LD + 4 * s + lg] : b[(4 * s + lg) * D3_LD + lr];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(NEG ? -av : av, bv, acc, 0, 0, 0);
+    }
+    return acc;
 }
 
-// One-image form: L goes to the lower part of the block, X = L^-1 transposed to the strictly upper part, its diagonal
-// to tdiag (see tri_t).
-__device__ __forceinline__ void diag16_factor_invert(float* a, float* tdiag, int j0, int* info, int col0, int lane) {
-    const int r = lane & 15;
+// D = a * R with R held in accumulator layout by the calling wave (lane: R[4 lg + e][lr]): the MFMA's k index is only a
+// summation index, so step s takes k = 4 lg + s -- B operand = the lane's own breg[s], A operand = a[lr][4 lg + s].
+// No staging through LDS.
+__device__ __forceinline__ f32x4 d3_mma_regb(const float* a, f32x4 breg, int lr, int lg) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[lr * D3_LD + 4 * lg + s], breg[s], acc, 0, 0, 0);
+    return acc;
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for the wave's outstanding GLOBAL stores
+// (vmcnt(0)) -- here the final L and T tiles stream out to HBM in every step and nobody in the workgroup reads them back,
+// so waiting for their acknowledgement (1-2 us each time) is pure loss.
+__device__ __forceinline__ void d3_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ void d3_put(float* tile, f32x4 acc, int lr, int lg) {   // accumulator layout -> row-major tile
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tile[(4 * lg + e) * D3_LD + lr] = acc[e];
+}
+
+// factor + invert the diagonal tile held in `acc` (by the calling wave): L to global (lower part), Dinv to `dinv` and to T
+__device__ __forceinline__ void d3_diag16(f32x4 acc, float* stage, float* dinv, gfloat* Sjj, int64_t ld, gfloat* Tjj, int* info, int col0,
+                                          int lane, int lr, int lg) {
+    d3_put(stage, acc, lr, lg);
+    __builtin_amdgcn_wave_barrier();
     float d[16], x[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
-        d[c] = a[(j0 + r) * LDA + j0 + c];
-        x[c] = (c == r) ? 1.f : 0.f;
+        d[c] = stage[lr * D3_LD + c];
+        x[c] = (c == lr) ? 1.f : 0.f;
     }
-    int bad = 0;                                           // first non-positive / NaN pivot, reported once below
-    diag16_pivots<0>(d, x, r, bad);
+    int bad = 0;
+    diag16_pivots<0>(d, x, lr, bad);
     diag16_report(bad, info, col0, lane);
-    if (lane < 16) {
+    // all four 16-lane rows hold the same d[], x[]: row lg writes columns 4 lg .. 4 lg + 3 (a quarter of the stores each)
 #pragma unroll
-        for (int c = 0; c < 16; ++c) a[(j0 + r) * LDA + j0 + c] = (c <= r) ? d[c] : x[c];   // X[c][r], c > r, at a[r][c]
-        tdiag[j0 + r] = x[r];
+    for (int c = 0; c < 16; ++c) {
+        if ((c >> 2) == lg) {
+            if (c <= lr) Sjj[(int64_t)lr * ld + c] = d[c];
+            dinv[c * D3_LD + lr] = x[c];                   // X[c][lr]
+            Tjj[c * NB + lr] = x[c];
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void potrf_diag_kernel(float* __restrict__ S, int64_t ld, int64_t k0, float* __restrict__ tinv,
-                                                          int* __restrict__ info, int block_index, const BatchMat* __restrict__ mats) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
+// wave 0: the diagonal tiles
+__device__ __forceinline__ void d3_diagonal_wave(gfloat* Sb, int64_t ld, gfloat* Tg, const float* Pp, float* dinvb, float* stage, int* info,
+                                                 int col0, int lane, int lr, int lg) {
+    f32x4 accD[8];
+#pragma unroll
+    for (int J = 0; J < 8; ++J)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) accD[J][e] = Sb[(int64_t)(16 * J + 4 * lg + e) * ld + 16 * J + lr];
+    d3_diag16(accD[0], stage, dinvb, Sb, ld, Tg, info, col0, lane, lr, lg);
+#pragma unroll
+    for (int J = 0; J < 8; ++J) {
+        d3_barrier();                      // Dinv_J is in LDS; every wave is done with step J-1
+        d3_barrier();                      // the panel and row J of X are in LDS
+        if (J == 7) break;
+        // look-ahead: (J+1, J+1) first, factored at once; the later diagonal tiles after that
+        const float* pj = Pp + (J + 1) * D3_TILE;
+        accD[J + 1] = d3_mma<true, true>(accD[J + 1], pj, pj, lr, lg);
+        d3_diag16(accD[J + 1], stage, dinvb + ((J + 1) & 1) * D3_TILE, Sb + (int64_t)16 * (J + 1) * ld + 16 * (J + 1), ld,
+                  Tg + 16 * (J + 1) * NB + 16 * (J + 1), info, col0 + 16 * (J + 1), lane, lr, lg);
+#pragma unroll
+        for (int K = J + 2; K < 8; ++K) accD[K] = d3_mma<true, true>(accD[K], Pp + K * D3_TILE, Pp + K * D3_TILE, lr, lg);
+    }
+}
+
+// waves 1..3: the off-diagonal tiles idx = 3 t + W - 1
+template <int W>
+__device__ __forceinline__ void d3_worker_wave(gfloat* Sb, int64_t ld, gfloat* Tg, float* Pp, float* Xr, const float* dinvb, int lr, int lg) {
+    constexpr int NS = (28 - (W - 1) + 2) / 3;
+    f32x4 acc[NS];
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+        const int I = d3_I(3 * t + W - 1), K = d3_K(3 * t + W - 1);
+        acc[t] = *reinterpret_cast<const gf32x4*>(Sb + (int64_t)(16 * I + lr) * ld + 16 * K + 4 * lg);            // A[I,K]^T
+        *reinterpret_cast<gf32x4*>(Tg + (16 * K + lr) * NB + 16 * I + 4 * lg) = f32x4{0.f, 0.f, 0.f, 0.f};        // T is lower triangular
+    }
+#pragma unroll
+    for (int J = 0; J < 8; ++J) {
+        const float* dinv = dinvb + (J & 1) * D3_TILE;
+        d3_barrier();                      // Dinv_J is in LDS; every wave is done with step J-1 (Pp, Xr may be rewritten)
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+            const int I = d3_I(3 * t + W - 1), K = d3_K(3 * t + W - 1);
+            if (K == J) {                  // panel tile: P_I^T = Dinv_J * A[I,J]^T, P_I = final L[I,J]; the slot turns to X[I,J]
+                const f32x4 pt = d3_mma_regb(dinv, acc[t], lr, lg);             // lane: P_I[lr][4 lg + e]
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Pp[I * D3_TILE + lr * D3_LD + 4 * lg + e] = pt[e];
+                *reinterpret_cast<gf32x4*>(Sb + (int64_t)(16 * I + lr) * ld + 16 * J + 4 * lg) = pt;
+                acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            } else if (I == J) {           // row J of the inverse (K < J): X[J,K] = Dinv_J * acc
+                const f32x4 xf = d3_mma_regb(dinv, acc[t], lr, lg);
+                d3_put(Xr + K * D3_TILE, xf, lr, lg);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Tg[(16 * J + 4 * lg + e) * NB + 16 * K + lr] = xf[e];
+            }
+        }
+        d3_barrier();                      // the panel and row J of X are in LDS
+        if (J == 7) break;
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+            const int I = d3_I(3 * t + W - 1), K = d3_K(3 * t + W - 1);
+            if (I > J) {
+                if (K > J) acc[t] = d3_mma<true, true>(acc[t], Pp + K * D3_TILE, Pp + I * D3_TILE, lr, lg);          // A[I,K]^T -= P_K P_I^T
+                else acc[t] = d3_mma<true, false>(acc[t], Pp + I * D3_TILE, K == J ? dinv : Xr + K * D3_TILE, lr, lg);   // X[I,K] -= L[I,J] X[J,K]
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(D3_THREADS, 4) void potrf_diag3_kernel(float* __restrict__ S, int64_t ld, int64_t k0, float* __restrict__ tinv,
+                                                                    int* __restrict__ info, int block_index, const BatchMat* __restrict__ mats) {
+    __shared__ float Pp[8 * D3_TILE], Xr[8 * D3_TILE], dinvb[2 * D3_TILE], stage[D3_TILE];
     if (mats) {                            // batched: workgroup = matrix blockIdx.x of the table (largest first)
         const BatchMat bm = mats[blockIdx.x];
         if (block_index >= bm.mpb) return;
@@ -730,353 +842,15 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(float* __restrict__ S, 
         ld = bm.ld;
         tinv = bm.tinv;
     }
-    float* a = sm;                         // [128][LDA]: L below/on the diagonal, T^T above it
-    float* tdiag = sm + NB * LDA;          // [128]: diagonal of T
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lg = lane >> 4;
-    float* Sb = S + k0 * ld + k0;
-    {   // 16 independent 16-byte loads per thread, issued together (row = (tid>>5)+8p, 4 columns at (tid&31)*4).
-        // Row stride 130 floats keeps (r, c) with c % 4 == 0 8-byte aligned: two ds_write_b64 per quad.
-        float4 v[16];
-#pragma unroll
-        for (int p = 0; p < 16; ++p) v[p] = *reinterpret_cast<const float4*>(Sb + (int64_t)((tid >> 5) + 8 * p) * ld + (tid & 31) * 4);
-#pragma unroll
-        for (int p = 0; p < 16; ++p) {
-            const int r = (tid >> 5) + 8 * p, c = (tid & 31) * 4;
-            float2* q = reinterpret_cast<float2*>(a + r * LDA + c);
-            q[0] = make_float2((c + 0 <= r) ? v[p].x : 0.f, (c + 1 <= r) ? v[p].y : 0.f);
-            q[1] = make_float2((c + 2 <= r) ? v[p].z : 0.f, (c + 3 <= r) ? v[p].w : 0.f);
-        }
-    }
-    __syncthreads();
-    // Look-ahead: while waves 1-3 apply the trailing update of block column J, wave 0 updates only the next
-    // diagonal block and immediately factors/inverts it, so the serial 16x16 factorizations (the longest
-    // single-wave stretch) hide behind the MFMA updates instead of adding to them.
-    if (w == 0) diag16_factor_invert(a, tdiag, 0, info, (int)k0, lane);
-    __syncthreads();
-    for (int J = 0; J < 8; ++J) {
-        const int j0 = 16 * J;
-        for (int I = J + 1 + w; I < 8; I += 4) {          // panel: P_I = A[I,J] * Dinv^T
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const float av = a[(16 * I + lr) * LDA + j0 + 4 * s + lg];
-                const float bv = tri_t(a, tdiag, j0, lr, 4 * s + lg);          // B[k][j] = Dinv[j][k], j = lr, k = 4s+lg
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) a[(16 * I + 4 * lg + e) * LDA + j0 + lr] = acc[e];
-        }
-        __syncthreads();
-        if (J == 7) break;
-        const int n = 7 - J, np = n * (n + 1) / 2;        // trailing pairs (I >= K > J); pair 0 = (J+1, J+1)
-        const int pfirst = (w == 0) ? 0 : w, pstep = (w == 0) ? np : 3;          // wave 0: pair 0 only
-        for (int p = pfirst; p < np; p += pstep) {
-            int kk = 0, rem = p;
-            while (rem >= n - kk) { rem -= n - kk; ++kk; }
-            const int K = J + 1 + kk, I = K + rem;
-            f32x4 acc;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] = a[(16 * I + 4 * lg + e) * LDA + 16 * K + lr];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const float av = -a[(16 * I + lr) * LDA + j0 + 4 * s + lg];
-                const float bv = a[(16 * K + lr) * LDA + j0 + 4 * s + lg];
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
-            }
-            // a diagonal pair (I == K) also rewrites the upper half of its block: harmless, block K is not factored yet
-#pragma unroll
-            for (int e = 0; e < 4; ++e) a[(16 * I + 4 * lg + e) * LDA + 16 * K + lr] = acc[e];
-        }
-        if (w == 0) diag16_factor_invert(a, tdiag, j0 + 16, info, (int)(k0 + j0 + 16), lane);
-        __syncthreads();
-    }
-    // ---- T = L^-1 by doubling; the diagonal 16-blocks of T are already in place ---------------------------------
-    for (int hb = 1; hb <= 4; hb *= 2) {                   // half size in 16-blocks
-        const int h = 16 * hb, npairs = 8 / (2 * hb), nout = npairs * hb * hb;       // 4, 8, 16 output tiles
-        // phase A: X = L21 * T11 -> the upper block (rows c0.., columns c0+h..) that T21^T will occupy
-        for (int o = w; o < nout; o += 4) {
-            const int pr = o / (hb * hb), bi = (o / hb) % hb, bj = o % hb;
-            const int c0 = pr * 2 * h;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            for (int kb = bj; kb < hb; ++kb) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const float av = a[(c0 + h + 16 * bi + lr) * LDA + c0 + 16 * kb + 4 * s + lg];
-                    // B[k][j] = T11[k][j], k = 16kb+4s+lg >= j = 16bj+lr off the diagonal sub-block: stored at a[c0+j][c0+k]
-                    const float bv = (kb == bj) ? tri_t(a, tdiag, c0 + 16 * bj, 4 * s + lg, lr)
-                                                : a[(c0 + 16 * bj + lr) * LDA + c0 + 16 * kb + 4 * s + lg];
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) a[(c0 + 16 * bi + 4 * lg + e) * LDA + c0 + h + 16 * bj + lr] = acc[e];
-        }
-        __syncthreads();
-        // phase B: T21 = -T22 * X, written TRANSPOSED over X's block: every tile is held in registers until all reads are done
-        f32x4 tb[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int o = w + 4 * q;
-            tb[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (o < nout) {
-                const int pr = o / (hb * hb), bi = (o / hb) % hb, bj = o % hb;
-                const int c0 = pr * 2 * h;
-                for (int kb = 0; kb <= bi; ++kb) {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        // A[i][k] = -T22[i][k], i = 16bi+lr, k = 16kb+4s+lg <= i: stored at a[c0+h+k][c0+h+i]
-                        const float tv = (kb == bi) ? tri_t(a, tdiag, c0 + h + 16 * bi, lr, 4 * s + lg)
-                                                    : a[(c0 + h + 16 * kb + 4 * s + lg) * LDA + c0 + h + 16 * bi + lr];
-                        const float bv = a[(c0 + 16 * kb + 4 * s + lg) * LDA + c0 + h + 16 * bj + lr];        // X[k][j]
-                        tb[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(-tv, bv, tb[q], 0, 0, 0);
-                    }
-                }
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int o = w + 4 * q;
-            if (o < nout) {
-                const int pr = o / (hb * hb), bi = (o / hb) % hb, bj = o % hb;
-                const int c0 = pr * 2 * h;
-                // T21[i][j], i = 16bi+4lg+e, j = 16bj+lr  ->  a[c0+j][c0+h+i]: four consecutive floats per lane
-                float2* q2 = reinterpret_cast<float2*>(a + (c0 + 16 * bj + lr) * LDA + c0 + h + 16 * bi + 4 * lg);
-                q2[0] = make_float2(tb[q][0], tb[q][1]);
-                q2[1] = make_float2(tb[q][2], tb[q][3]);
-            }
-        }
-        __syncthreads();
-    }
-    // ---- store L (lower triangle of S) and T (row-major 128x128, zero above the diagonal) -----------------------
-#pragma unroll
-    for (int hp = 0; hp < 2; ++hp) {       // LDS reads of 8 rows first (ds_read_b64), then their stores
-        float2 ql[8][2];
-#pragma unroll
-        for (int pp = 0; pp < 8; ++pp) {
-            const int r = (tid >> 5) + 8 * (hp * 8 + pp), c = (tid & 31) * 4;
-            const float2* q = reinterpret_cast<const float2*>(a + r * LDA + c);
-            ql[pp][0] = q[0]; ql[pp][1] = q[1];
-        }
-#pragma unroll
-        for (int pp = 0; pp < 8; ++pp) {
-            const int r = (tid >> 5) + 8 * (hp * 8 + pp), c = (tid & 31) * 4;
-            float* g = Sb + (int64_t)r * ld + c;
-            if (c + 3 <= r) *reinterpret_cast<float4*>(g) = make_float4(ql[pp][0].x, ql[pp][0].y, ql[pp][1].x, ql[pp][1].y);
-            else {
-                if (c + 0 <= r) g[0] = ql[pp][0].x;
-                if (c + 1 <= r) g[1] = ql[pp][0].y;
-                if (c + 2 <= r) g[2] = ql[pp][1].x;
-            }
-        }
-    }
-    // T[r][c] = a[c][r] (c < r): a transposed read.  Lane -> (row r = r0 + (lane & 15), quad of columns (lane >> 4)):
-    // the 64 reads of one instruction fall on 4 image rows x 16 consecutive words (2 lanes per bank), and the float4
-    // stores of a wave cover 16 rows x 64 contiguous bytes of the row-major T.
-    float* Tg = tinv + (int64_t)block_index * NB * NB;
-    for (int it = 0; it < 16; ++it) {
-        const int item = it * 4 + w;                       // 64 items: 8 row groups of 16 x 8 column groups of 16
-        const int r = 16 * (item >> 3) + lr, c = 16 * (item & 7) + 4 * lg;
-        float o4[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int cc = c + q;
-            const float up = a[(cc < r ? cc : r) * LDA + (cc < r ? r : cc)];
-            o4[q] = cc < r ? up : (cc == r ? tdiag[r] : 0.f);
-        }
-        *reinterpret_cast<float4*>(Tg + r * NB + c) = make_float4(o4[0], o4[1], o4[2], o4[3]);
-    }
+    gfloat* Sb = (gfloat*)(S + k0 * ld + k0);
+    gfloat* Tg = (gfloat*)(tinv + (int64_t)block_index * NB * NB);
+    if (w == 0) d3_diagonal_wave(Sb, ld, Tg, Pp, dinvb, stage, info, (int)k0, lane, lr, lg);
+    else if (w == 1) d3_worker_wave<1>(Sb, ld, Tg, Pp, Xr, dinvb, lr, lg);
+    else if (w == 2) d3_worker_wave<2>(Sb, ld, Tg, Pp, Xr, dinvb, lr, lg);
+    else d3_worker_wave<3>(Sb, ld, Tg, Pp, Xr, dinvb, lr, lg);
 }
-
-// ---- diagonal block, TWO LDS images (the default): Cholesky + inverse of one 128x128 block, one workgroup ------------
-// 33 us per block against 43 us for the one-image kernel above (its masked operand reads, the register-held T21 tiles
-// and the transposed store of T cost 10 us), at 137 KB of LDS: the workgroup needs a CU to itself.  That is what it
-// gets in the recursive single-matrix schedule and in a batched (lock-step) factorization -- nothing else runs on the
-// stream's critical path -- so both use this kernel; lane-concurrent analyses (TiledAnalysis(batched=False), where a
-// diagonal block of one tile must squeeze in next to the GEMMs of another) select the 67 KB kernel (oisat_diag_lds).
-// Right-looking at 16-column granularity, 4 waves.  Per block column J:
-//   (1) wave 0 factors the 16x16 diagonal block in registers (lane = row, columns in VGPRs, pivots
-//       broadcast with v_readlane) and inverts it the same way;
-//   (2) panel below:   P_I  = A[I,J] * Dinv_J^T          (v_mfma_f32_16x16x4_f32, 4 per 16x16 block)
-//   (3) trailing:      A[I,K] -= P_I * P_K^T,  J < K <= I
-// then T = L^-1 by doubling (16 -> 32 -> 64 -> 128):  T21 = -T22 * (L21 * T11), both products on
-// MFMA; the intermediate L21*T11 is parked in the unused upper triangle of the L image.
-// LDS: a[128][130] (L), t[128][130] (T), dinv[8][16][17].  Row stride 130 = 2 mod 32 keeps the
-// (row = lane&15, k = lane>>4) MFMA operand reads conflict-free.
-constexpr int DINV_LD = 17;
-constexpr int DINV_SZ = 16 * DINV_LD;
-
-
-// Two-image form: L to the a image (upper part of the block zeroed), X = L^-1 to dinvJ[16][17].
-__device__ __forceinline__ void diag16_factor_invert2(float* a, int j0, float* dinvJ, int* info, int col0, int lane) {
-    const int r = lane & 15;
-    float d[16], x[16];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        d[c] = a[(j0 + r) * LDA + j0 + c];
-        x[c] = (c == r) ? 1.f : 0.f;                       // running delta_{c,r} - sum_{k<c} L[c][k] X[k][r]
-    }
-    int bad = 0;                                           // first non-positive / NaN pivot, reported once below
-    diag16_pivots<0>(d, x, r, bad);
-    diag16_report(bad, info, col0, lane);
-#pragma unroll
-    for (int c = 0; c < 16; ++c)
-        if (lane < 16) a[(j0 + r) * LDA + j0 + c] = (c <= r) ? d[c] : 0.f;
-#pragma unroll
-    for (int rr = 0; rr < 16; ++rr)
-        if (lane < 16) dinvJ[rr * DINV_LD + r] = x[rr];
-}
-
-constexpr int kDiag2Threads = 512, kDiag2Waves = kDiag2Threads / 64, kDiag2Rows = NB * 32 / kDiag2Threads;   // rows per thread in the 128x128 copies
-
-__global__ __launch_bounds__(kDiag2Threads) void potrf_diag2_kernel(float* __restrict__ S, int64_t ld, int64_t k0, float* __restrict__ tinv,
-                                                          int* __restrict__ info, int block_index, const BatchMat* __restrict__ mats) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    if (mats) {                            // batched: workgroup = matrix blockIdx.x of the table (largest first)
-        const BatchMat bm = mats[blockIdx.x];
-        if (block_index >= bm.mpb) return;
-        S = bm.S;
-        ld = bm.ld;
-        tinv = bm.tinv;
-    }
-    float* a = sm;                         // [128][LDA]
-    float* t = sm + NB * LDA;              // [128][LDA]
-    float* dinv = t + NB * LDA;            // [8][16][17]
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int lr = lane & 15, lg = lane >> 4;
-    float* Sb = S + k0 * ld + k0;
-    {   // independent 16-byte loads, issued together (row = (tid>>5) + 16p, 4 columns at (tid&31)*4).
-        // Row stride 130 floats keeps (r, c) with c % 4 == 0 8-byte aligned: two ds_write_b64 per quad.
-        // (t needs no clearing: every element of it that is read later has been written by then.)
-        float4 v[kDiag2Rows];
-#pragma unroll
-        for (int p = 0; p < kDiag2Rows; ++p)
-            v[p] = *reinterpret_cast<const float4*>(Sb + (int64_t)((tid >> 5) + (kDiag2Threads / 32) * p) * ld + (tid & 31) * 4);
-#pragma unroll
-        for (int p = 0; p < kDiag2Rows; ++p) {
-            const int r = (tid >> 5) + (kDiag2Threads / 32) * p, c = (tid & 31) * 4;
-            float2* q = reinterpret_cast<float2*>(a + r * LDA + c);
-            q[0] = make_float2((c + 0 <= r) ? v[p].x : 0.f, (c + 1 <= r) ? v[p].y : 0.f);
-            q[1] = make_float2((c + 2 <= r) ? v[p].z : 0.f, (c + 3 <= r) ? v[p].w : 0.f);
-        }
-    }
-    __syncthreads();
-    // Look-ahead: while the other waves apply the trailing update of block column J, wave 0 updates only the next
-    // diagonal block and immediately factors/inverts it, so the serial 16x16 factorizations (the longest
-    // single-wave stretch) hide behind the MFMA updates instead of adding to them.
-    if (w == 0) diag16_factor_invert2(a, 0, dinv, info, (int)k0, lane);
-    __syncthreads();
-    for (int J = 0; J < 8; ++J) {
-        const int j0 = 16 * J;
-        const float* dJ = dinv + J * DINV_SZ;
-        for (int I = J + 1 + w; I < 8; I += kDiag2Waves) { // panel: P_I = A[I,J] * Dinv^T
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const float av = a[(16 * I + lr) * LDA + j0 + 4 * s + lg];
-                const float bv = dJ[lr * DINV_LD + 4 * s + lg];               // B[k][j] = Dinv[j][k]
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) a[(16 * I + 4 * lg + e) * LDA + j0 + lr] = acc[e];
-        }
-        __syncthreads();
-        if (J == 7) break;
-        const int n = 7 - J, np = n * (n + 1) / 2;        // trailing pairs (I >= K > J); pair 0 = (J+1, J+1)
-        const int pfirst = (w == 0) ? 0 : w, pstep = (w == 0) ? np : kDiag2Waves - 1;   // wave 0: pair 0 only
-        for (int p = pfirst; p < np; p += pstep) {
-            int kk = 0, rem = p;
-            while (rem >= n - kk) { rem -= n - kk; ++kk; }
-            const int K = J + 1 + kk, I = K + rem;
-            f32x4 acc;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] = a[(16 * I + 4 * lg + e) * LDA + 16 * K + lr];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const float av = -a[(16 * I + lr) * LDA + j0 + 4 * s + lg];
-                const float bv = a[(16 * K + lr) * LDA + j0 + 4 * s + lg];
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) a[(16 * I + 4 * lg + e) * LDA + 16 * K + lr] = acc[e];
-        }
-        if (w == 0) diag16_factor_invert2(a, j0 + 16, dinv + (J + 1) * DINV_SZ, info, (int)(k0 + j0 + 16), lane);
-        __syncthreads();
-    }
-    // ---- T = L^-1 -----------------------------------------------------------------------------
-    for (int idx = tid; idx < 8 * 256; idx += kDiag2Threads) {   // diagonal 16-blocks of T
-        const int J = idx >> 8, rr = (idx >> 4) & 15, cc = idx & 15;
-        t[(16 * J + rr) * LDA + 16 * J + cc] = dinv[J * DINV_SZ + rr * DINV_LD + cc];
-    }
-    __syncthreads();
-    for (int hb = 1; hb <= 4; hb *= 2) {                   // half size in 16-blocks
-        const int h = 16 * hb, npairs = 8 / (2 * hb), nout = npairs * hb * hb;
-        // phase A: X = L21 * T11  -> upper mirror of a
-        for (int o = w; o < nout; o += kDiag2Waves) {
-            const int pr = o / (hb * hb), bi = (o / hb) % hb, bj = o % hb;
-            const int c0 = pr * 2 * h;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            for (int kb = bj; kb < hb; ++kb) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const float av = a[(c0 + h + 16 * bi + lr) * LDA + c0 + 16 * kb + 4 * s + lg];
-                    const float bv = t[(c0 + 16 * kb + 4 * s + lg) * LDA + c0 + 16 * bj + lr];
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) a[(c0 + 16 * bi + 4 * lg + e) * LDA + c0 + h + 16 * bj + lr] = acc[e];
-        }
-        __syncthreads();
-        // phase B: T21 = -T22 * X
-        for (int o = w; o < nout; o += kDiag2Waves) {
-            const int pr = o / (hb * hb), bi = (o / hb) % hb, bj = o % hb;
-            const int c0 = pr * 2 * h;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            for (int kb = 0; kb <= bi; ++kb) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const float av = -t[(c0 + h + 16 * bi + lr) * LDA + c0 + h + 16 * kb + 4 * s + lg];
-                    const float bv = a[(c0 + 16 * kb + 4 * s + lg) * LDA + c0 + h + 16 * bj + lr];
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) t[(c0 + h + 16 * bi + 4 * lg + e) * LDA + c0 + 16 * bj + lr] = acc[e];
-        }
-        __syncthreads();
-    }
-    float* Tg = tinv + (int64_t)block_index * NB * NB;
-#pragma unroll
-    for (int hp = 0; hp < kDiag2Rows / 8; ++hp) {   // LDS reads of 8 rows first (ds_read_b64), then their stores
-        float2 ql[8][2], zl[8][2];
-#pragma unroll
-        for (int pp = 0; pp < 8; ++pp) {
-            const int r = (tid >> 5) + (kDiag2Threads / 32) * (hp * 8 + pp), c = (tid & 31) * 4;
-            const float2* q = reinterpret_cast<const float2*>(a + r * LDA + c);
-            const float2* z = reinterpret_cast<const float2*>(t + r * LDA + c);
-            ql[pp][0] = q[0]; ql[pp][1] = q[1];
-            zl[pp][0] = z[0]; zl[pp][1] = z[1];
-        }
-#pragma unroll
-        for (int pp = 0; pp < 8; ++pp) {
-            const int r = (tid >> 5) + (kDiag2Threads / 32) * (hp * 8 + pp), c = (tid & 31) * 4;
-            float* g = Sb + (int64_t)r * ld + c;
-            if (c + 3 <= r) *reinterpret_cast<float4*>(g) = make_float4(ql[pp][0].x, ql[pp][0].y, ql[pp][1].x, ql[pp][1].y);
-            else {
-                if (c + 0 <= r) g[0] = ql[pp][0].x;
-                if (c + 1 <= r) g[1] = ql[pp][0].y;
-                if (c + 2 <= r) g[2] = ql[pp][1].x;
-            }
-            // T above the diagonal was never written in LDS: select, do not multiply
-            *reinterpret_cast<float4*>(Tg + r * NB + c) = make_float4(c + 0 <= r ? zl[pp][0].x : 0.f, c + 1 <= r ? zl[pp][0].y : 0.f,
-                                                                       c + 2 <= r ? zl[pp][1].x : 0.f, c + 3 <= r ? zl[pp][1].y : 0.f);
-        }
-    }
-}
-
-constexpr size_t kDiag2Shm = sizeof(float) * (2 * NB * LDA + 8 * DINV_SZ);
 
 // identity padding of rows m..mp (columns 0..mp)
 __global__ __launch_bounds__(256) void pad_identity_kernel(float* __restrict__ S, int64_t ld, int64_t m, int64_t mp) {
@@ -1409,13 +1183,8 @@ int potrf_rec_batched(oisat_ctx* h, const ChBatch& bt, int b0, int b1, int* info
             ++cnt;
         }
         if (cnt == 0) return OISAT_OK;
-        if (h->diag_small_lds) {
-            OISAT_LAUNCH(h, "potrf_diag", potrf_diag_kernel, dim3((unsigned)cnt), dim3(256), kDiagShm, (float*)nullptr, (int64_t)0,
-                         (int64_t)b0 * NB, (float*)nullptr, info_dev, b0, (const BatchMat*)bt.table_dev);
-        } else {
-            OISAT_LAUNCH(h, "potrf_diag", potrf_diag2_kernel, dim3((unsigned)cnt), dim3(kDiag2Threads), kDiag2Shm, (float*)nullptr, (int64_t)0,
-                         (int64_t)b0 * NB, (float*)nullptr, info_dev, b0, (const BatchMat*)bt.table_dev);
-        }
+        OISAT_LAUNCH(h, "potrf_diag", potrf_diag3_kernel, dim3((unsigned)cnt), dim3(D3_THREADS), 0, (float*)nullptr, (int64_t)0,
+                     (int64_t)b0 * NB, (float*)nullptr, info_dev, b0, (const BatchMat*)bt.table_dev);
         return launch_gemm_batched(h, "trsm_gemm", bt, BatchArgs{bt.table_dev, 1, b0, 0, 0}, NB, 1, 0);
     }
     static const bool pow2 = getenv("OISAT_BATCH_TREE") && !strcmp(getenv("OISAT_BATCH_TREE"), "pow2");
@@ -1444,13 +1213,8 @@ __global__ __launch_bounds__(256) void pad_identity_batched_kernel(const BatchMa
 int potrf_rec(oisat_ctx* h, float* S, int64_t ld, int64_t mpb, int64_t b0, int64_t b1, float* tinv, int* info_dev) {
     if (b1 - b0 == 1) {
         const int64_t k0 = b0 * NB;
-        if (h->diag_small_lds) {
-            OISAT_LAUNCH(h, "potrf_diag", potrf_diag_kernel, dim3(1), dim3(256), kDiagShm, S, ld, k0, tinv, info_dev, (int)b0,
-                         (const BatchMat*)nullptr);
-        } else {
-            OISAT_LAUNCH(h, "potrf_diag", potrf_diag2_kernel, dim3(1), dim3(kDiag2Threads), kDiag2Shm, S, ld, k0, tinv, info_dev, (int)b0,
-                         (const BatchMat*)nullptr);
-        }
+        OISAT_LAUNCH(h, "potrf_diag", potrf_diag3_kernel, dim3(1), dim3(D3_THREADS), 0, S, ld, k0, tinv, info_dev, (int)b0,
+                     (const BatchMat*)nullptr);
         const int64_t rows = (mpb - b0 - 1) * NB;
         if (rows > 0) {
             float* P = S + (k0 + NB) * ld + k0;                  // panel below the diagonal block
@@ -1608,12 +1372,7 @@ int trsm_rows_rec(oisat_ctx* h, const ChFactor& f, float* X, int64_t nrows, int6
 // per-function attributes, set once per process (handles may be driven from different host threads)
 hipError_t dense_kernel_attributes() {
     static const hipError_t attr_rc = []() {
-        hipError_t e = hipFuncSetAttribute((const void*)potrf_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)kDiagShm);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)potrf_diag2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDiag2Shm);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)trsv_pipe_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute((const void*)trsv_pipe_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)(sizeof(float) * NB * TLD));
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)trsv_pipe_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1945,8 +1704,3 @@ extern "C" int oisat_factor_adopt(oisat_ctx* h, const float* L, int64_t m, int64
     return OISAT_OK;
 }
 
-extern "C" int oisat_diag_lds(oisat_ctx* h, int small) {
-    ARG_CHECK(h != nullptr);
-    h->diag_small_lds = small != 0;
-    return OISAT_OK;
-}

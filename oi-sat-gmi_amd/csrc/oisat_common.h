@@ -70,7 +70,6 @@ struct oisat_ctx {
     const void* scales_dev = nullptr;
     // the factor left by the last oisat_potrf on this handle (dense_chol.hip)
     ChFactor factor;
-    bool diag_small_lds = false;        // potrf_diag: the 67 KB one-image kernel instead of the 137 KB two-image one (oisat_diag_lds)
     bool small_tiles = true;            // gemm_nt: 64x64 tiles for launches of <= 700 128x128 tiles (latency-bound ones)
     hipStream_t own_stream = nullptr;   // created by oisat_stream_create, destroyed at shutdown
     hipStream_t aux_stream = nullptr;   // look-ahead Cholesky: trailing updates run here, the panel chain on `stream`

@@ -75,7 +75,6 @@ SIGNATURES = {
     "oisat_innovation": (C.c_int, [_c_ctx, C.c_int, _ptr, _ptr, _ptr, _i64, _ptr]),
     "oisat_gemm_nt": (C.c_int, [_c_ctx, _ptr, _i64, _ptr, _i64, _ptr, _i64, _i64, _i64, _i64, C.c_int, C.c_int]),
     "oisat_potrf": (C.c_int, [_c_ctx, _ptr, _i64, _i64, C.POINTER(C.c_int)]),
-    "oisat_diag_lds": (C.c_int, [_c_ctx, C.c_int]),
     "oisat_potrs": (C.c_int, [_c_ctx, _ptr, _i64, _i64, _ptr]),
     "oisat_cov_residual": (C.c_int, [_c_ctx, _ptr, _ptr, _ptr, _i64, C.c_double, _ptr, _ptr, _ptr, _ptr]),
     "oisat_gain_solve": (C.c_int, [_c_ctx, _ptr, _ptr, _ptr, _ptr, _i64, _i64, C.c_double, _ptr, C.c_int, _ptr,

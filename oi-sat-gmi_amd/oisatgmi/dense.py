@@ -503,8 +503,6 @@ class TiledAnalysis:
         self.pool = pool or LanePool(ctx, streams)
         self.ctx = self.pool.ctx
         self.lanes = self.pool.lanes
-        for lane in self.lanes:                          # lane-concurrent factorizations want the diagonal kernel that
-            lane.check(lane.lib.oisat_diag_lds(lane.h, 0 if self.batched else 1))   # fits next to another lane's GEMMs
         self.lat2, self.lon2 = np.asarray(grid_lat), np.asarray(grid_lon)
         self.tile_deg, self.halo_km = float(tile_deg), float(halo_km)
         self.dt = np.dtype(dtype)
@@ -604,9 +602,6 @@ class TiledAnalysis:
             self.factor.close()
             self.factor = None
         self.plans = []
-        for lane in self.lanes:
-            if lane.h is not None:
-                lane.lib.oisat_diag_lds(lane.h, 0)
         if self._own_pool:
             self.pool.close()
 
