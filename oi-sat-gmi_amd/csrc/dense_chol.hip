@@ -636,31 +636,42 @@ __device__ __forceinline__ void diag16_settle(float& dk, float& xk) {
     asm volatile("s_nop 1" : "+v"(dk), "+v"(xk));
 }
 
-template <int K, int C>
+template <int K, int C, int CEND>            // columns C .. CEND-1 receive pivot K's update
 __device__ __forceinline__ void diag16_columns(float (&d)[16], float (&x)[16]) {
-    if constexpr (C < 16) {
+    if constexpr (C < CEND) {
         asm volatile("v_fmac_f32_dpp %0, -%2, %2 row_newbcast:%4 row_mask:0xf bank_mask:0xf\n\t"
                      "v_fmac_f32_dpp %1, -%2, %3 row_newbcast:%4 row_mask:0xf bank_mask:0xf"
                      : "+v"(d[C]), "+v"(x[C]) : "v"(d[K]), "v"(x[K]), "n"(C));
-        diag16_columns<K, C + 1>(d, x);
+        diag16_columns<K, C + 1, CEND>(d, x);
     }
 }
 
+// pivot K: broadcast, reciprocal square root (+ one Newton step), scale column K of L and row K of X.  Plain C between
+// the asm blocks: the compiler is free to spread these dependent instructions among the (independent) FMAs of the
+// previous pivot that follow in program order.
+template <int K>
+__device__ __forceinline__ void diag16_pivot(float (&d)[16], float (&x)[16], int r, int& bad) {
+    float piv = row16_bcast_settled<K>(d[K]);
+    const bool neg = !(piv > 0.f);
+    bad = (neg && bad == 0) ? K + 1 : bad;
+    piv = neg ? 1.f : piv;
+    float ri = __builtin_amdgcn_rsqf(piv);
+    ri = ri * (1.5f - 0.5f * piv * ri * ri);              // one Newton step: ~0.5 ulp
+    d[K] = (r == K) ? piv * ri : d[K] * ri;               // L[k][k] = sqrt(piv); column k of L
+    x[K] = (K >= r) ? x[K] * ri : 0.f;                    // X[k][:] /= L[k][k]
+}
+
+// Software-pipelined sweep: as soon as column K+1 has received pivot K's update, pivot K+1's dependent chain
+// (broadcast -> rsq -> Newton -> scale) is started, and the remaining updates of pivot K (columns K+2..15, independent
+// of it) fill its latency.  Same arithmetic in the same order as the plain sweep.
 template <int K>
 __device__ __forceinline__ void diag16_pivots(float (&d)[16], float (&x)[16], int r, int& bad) {
-    if constexpr (K < 16) {
-        float piv = row16_bcast_settled<K>(d[K]);
-        const bool neg = !(piv > 0.f);
-        bad = (neg && bad == 0) ? K + 1 : bad;
-        piv = neg ? 1.f : piv;
-        float ri = __builtin_amdgcn_rsqf(piv);
-        ri = ri * (1.5f - 0.5f * piv * ri * ri);          // one Newton step: ~0.5 ulp
-        d[K] = (r == K) ? piv * ri : d[K] * ri;           // L[k][k] = sqrt(piv); column k of L
-        x[K] = (K >= r) ? x[K] * ri : 0.f;                // X[k][:] /= L[k][k]
-        if constexpr (K < 15) {
-            diag16_settle(d[K], x[K]);
-            diag16_columns<K, K + 1>(d, x);
-        }
+    if constexpr (K == 0) diag16_pivot<0>(d, x, r, bad);
+    if constexpr (K < 15) {
+        diag16_settle(d[K], x[K]);
+        diag16_columns<K, K + 1, K + 2>(d, x);             // column K+1 is final
+        diag16_pivot<K + 1>(d, x, r, bad);
+        diag16_columns<K, K + 2, 16>(d, x);
         diag16_pivots<K + 1>(d, x, r, bad);
     }
 }
@@ -674,7 +685,7 @@ __device__ __forceinline__ void diag16_report(int bad, int* info, int col0, int 
     }
 }
 
-// ---- diagonal block, REGISTER-RESIDENT: Cholesky + inverse of one 128x128 block, one workgroup of 4 waves, 20 KB of LDS ------
+// ---- diagonal block, REGISTER-RESIDENT: Cholesky + inverse of one 128x128 block, one workgroup of 4 waves, 24 KB of LDS ------
 // The 36 lower 16x16 tiles of the block live in MFMA accumulator registers for the whole kernel: the 8 diagonal tiles in
 // wave 0 (which also runs the serial 16x16 factorizations), off-diagonal tile (I, K), idx = I(I-1)/2 + K, in wave
 // 1 + idx % 3, slot idx / 3 (10 / 9 / 9 tiles).  A slot's accumulator holds A[I,K] until its panel step K makes it the
@@ -695,7 +706,7 @@ __device__ __forceinline__ void diag16_report(int bad, int* info, int col0, int 
 // of (J+1, J+1) updates that tile first and factors it while the other waves finish step J (look-ahead).
 typedef __attribute__((address_space(1))) float gfloat;          // global address space: global_load / global_store, which the
 typedef __attribute__((address_space(1))) f32x4 gf32x4;         // LDS-only barrier does not wait for (flat_* count on lgkmcnt too)
-constexpr int D3_WAVES = 4, D3_THREADS = 64 * D3_WAVES, D3_LD = 17, D3_TILE = 16 * D3_LD;
+constexpr int D3_WAVES = 4, D3_THREADS = 64 * D3_WAVES, D3_LD = 17, D3_TILE = 16 * D3_LD, D3_PBUF = 7 * D3_TILE;
 
 constexpr int d3_I(int idx) {              // idx = I(I-1)/2 + K, 0 <= K < I < 8
     int I = 1;
@@ -739,58 +750,77 @@ __device__ __forceinline__ void d3_put(float* tile, f32x4 acc, int lr, int lg) {
     for (int e = 0; e < 4; ++e) tile[(4 * lg + e) * D3_LD + lr] = acc[e];
 }
 
-// factor + invert the diagonal tile held in `acc` (by the calling wave): L to global (lower part), Dinv to `dinv` and to T
-__device__ __forceinline__ void d3_diag16(f32x4 acc, float* stage, float* dinv, gfloat* Sjj, int64_t ld, gfloat* Tjj, int* info, int col0,
-                                          int lane, int lr, int lg) {
-    d3_put(stage, acc, lr, lg);
+// factor + invert the diagonal tile held in `acc` (by the calling wave): L16 (full rows, the upper part is garbage) to
+// `stage`, X16 = L16^-1 to `dinv`; a worker wave copies both to global memory in the next panel phase
+constexpr int D3_SLD = 20;                 // row stride of the staging tile: 16-byte aligned rows (ds_read_b128 / ds_write_b128)
+__device__ __forceinline__ void d3_diag16(f32x4 acc, float* stage, float* dinv, int* info, int col0, int lane, int lr, int lg) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) stage[(4 * lg + e) * D3_SLD + lr] = acc[e];
     __builtin_amdgcn_wave_barrier();
     float d[16], x[16];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        d[c] = stage[lr * D3_LD + c];
-        x[c] = (c == lr) ? 1.f : 0.f;
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(stage + lr * D3_SLD + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[4 * q + e] = v[e];
     }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) x[c] = (c == lr) ? 1.f : 0.f;
     int bad = 0;
     diag16_pivots<0>(d, x, lr, bad);
     diag16_report(bad, info, col0, lane);
-    // all four 16-lane rows hold the same d[], x[]: row lg writes columns 4 lg .. 4 lg + 3 (a quarter of the stores each)
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 16) {                       // (the other three 16-lane rows hold copies)
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        if ((c >> 2) == lg) {
-            if (c <= lr) Sjj[(int64_t)lr * ld + c] = d[c];
-            dinv[c * D3_LD + lr] = x[c];                   // X[c][lr]
-            Tjj[c * NB + lr] = x[c];
-        }
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<f32x4*>(stage + lr * D3_SLD + 4 * q) = f32x4{d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]};   // L16[lr][:]
+#pragma unroll
+        for (int c = 0; c < 16; ++c) dinv[c * D3_LD + lr] = x[c];                                                             // X16[c][lr]
     }
 }
 
+// a worker copies the freshly factored diagonal tile J to global memory: L16 (lower part) and T's diagonal tile
+__device__ __forceinline__ void d3_store_diag(gfloat* Sjj, int64_t ld, gfloat* Tjj, const float* stage, const float* dinv, int lr, int lg) {
+    const f32x4 l = *reinterpret_cast<const f32x4*>(stage + lr * D3_SLD + 4 * lg);
+    f32x4 t;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        t[e] = dinv[lr * D3_LD + 4 * lg + e];
+        if (4 * lg + e <= lr) Sjj[(int64_t)lr * ld + 4 * lg + e] = l[e];
+    }
+    *reinterpret_cast<gf32x4*>(Tjj + lr * NB + 4 * lg) = t;
+}
+
 // wave 0: the diagonal tiles
-__device__ __forceinline__ void d3_diagonal_wave(gfloat* Sb, int64_t ld, gfloat* Tg, const float* Pp, float* dinvb, float* stage, int* info,
+__device__ __forceinline__ void d3_diagonal_wave(gfloat* Sb, int64_t ld, const float* Pp, float* dinvb, float* stage, int* info,
                                                  int col0, int lane, int lr, int lg) {
     f32x4 accD[8];
 #pragma unroll
     for (int J = 0; J < 8; ++J)
 #pragma unroll
         for (int e = 0; e < 4; ++e) accD[J][e] = Sb[(int64_t)(16 * J + 4 * lg + e) * ld + 16 * J + lr];
-    d3_diag16(accD[0], stage, dinvb, Sb, ld, Tg, info, col0, lane, lr, lg);
+    d3_diag16(accD[0], stage, dinvb, info, col0, lane, lr, lg);
 #pragma unroll
     for (int J = 0; J < 8; ++J) {
         d3_barrier();                      // Dinv_J is in LDS; every wave is done with step J-1
+        if (J >= 1) {                      // while the workers build panel J: the later diagonal tiles catch up with panel J-1
+            const float* pp = Pp + ((J - 1) & 1) * D3_PBUF;
+#pragma unroll
+            for (int K = J + 1; K < 8; ++K) accD[K] = d3_mma<true, true>(accD[K], pp + (K - 1) * D3_TILE, pp + (K - 1) * D3_TILE, lr, lg);
+        }
         d3_barrier();                      // the panel and row J of X are in LDS
         if (J == 7) break;
-        // look-ahead: (J+1, J+1) first, factored at once; the later diagonal tiles after that
-        const float* pj = Pp + (J + 1) * D3_TILE;
+        // look-ahead: tile (J+1, J+1) takes panel J's update and is factored at once (its older updates are in already)
+        const float* pj = Pp + (J & 1) * D3_PBUF + J * D3_TILE;
         accD[J + 1] = d3_mma<true, true>(accD[J + 1], pj, pj, lr, lg);
-        d3_diag16(accD[J + 1], stage, dinvb + ((J + 1) & 1) * D3_TILE, Sb + (int64_t)16 * (J + 1) * ld + 16 * (J + 1), ld,
-                  Tg + 16 * (J + 1) * NB + 16 * (J + 1), info, col0 + 16 * (J + 1), lane, lr, lg);
-#pragma unroll
-        for (int K = J + 2; K < 8; ++K) accD[K] = d3_mma<true, true>(accD[K], Pp + K * D3_TILE, Pp + K * D3_TILE, lr, lg);
+        d3_diag16(accD[J + 1], stage, dinvb + ((J + 1) & 1) * D3_TILE, info, col0 + 16 * (J + 1), lane, lr, lg);
     }
 }
 
 // waves 1..3: the off-diagonal tiles idx = 3 t + W - 1
 template <int W>
-__device__ __forceinline__ void d3_worker_wave(gfloat* Sb, int64_t ld, gfloat* Tg, float* Pp, float* Xr, const float* dinvb, int lr, int lg) {
+__device__ __forceinline__ void d3_worker_wave(gfloat* Sb, int64_t ld, gfloat* Tg, float* Pp, float* Xr, const float* dinvb, const float* stage,
+                                               int lr, int lg) {
     constexpr int NS = (28 - (W - 1) + 2) / 3;
     f32x4 acc[NS];
 #pragma unroll
@@ -802,14 +832,17 @@ __device__ __forceinline__ void d3_worker_wave(gfloat* Sb, int64_t ld, gfloat* T
 #pragma unroll
     for (int J = 0; J < 8; ++J) {
         const float* dinv = dinvb + (J & 1) * D3_TILE;
-        d3_barrier();                      // Dinv_J is in LDS; every wave is done with step J-1 (Pp, Xr may be rewritten)
+        float* P = Pp + (J & 1) * D3_PBUF;                 // panel J: tile I (>= 1) at P + (I - 1) * D3_TILE; two buffers, by parity of J
+        d3_barrier();                      // Dinv_J is in LDS; every wave is done with step J-1 (P, Xr may be rewritten)
+        if (J % 3 == W - 1)                // the diagonal tile wave 0 has just factored: to global memory
+            d3_store_diag(Sb + (int64_t)16 * J * ld + 16 * J, ld, Tg + 16 * J * NB + 16 * J, stage, dinv, lr, lg);
 #pragma unroll
         for (int t = 0; t < NS; ++t) {
             const int I = d3_I(3 * t + W - 1), K = d3_K(3 * t + W - 1);
             if (K == J) {                  // panel tile: P_I^T = Dinv_J * A[I,J]^T, P_I = final L[I,J]; the slot turns to X[I,J]
                 const f32x4 pt = d3_mma_regb(dinv, acc[t], lr, lg);             // lane: P_I[lr][4 lg + e]
 #pragma unroll
-                for (int e = 0; e < 4; ++e) Pp[I * D3_TILE + lr * D3_LD + 4 * lg + e] = pt[e];
+                for (int e = 0; e < 4; ++e) P[(I - 1) * D3_TILE + lr * D3_LD + 4 * lg + e] = pt[e];
                 *reinterpret_cast<gf32x4*>(Sb + (int64_t)(16 * I + lr) * ld + 16 * J + 4 * lg) = pt;
                 acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
             } else if (I == J) {           // row J of the inverse (K < J): X[J,K] = Dinv_J * acc
@@ -825,8 +858,8 @@ __device__ __forceinline__ void d3_worker_wave(gfloat* Sb, int64_t ld, gfloat* T
         for (int t = 0; t < NS; ++t) {
             const int I = d3_I(3 * t + W - 1), K = d3_K(3 * t + W - 1);
             if (I > J) {
-                if (K > J) acc[t] = d3_mma<true, true>(acc[t], Pp + K * D3_TILE, Pp + I * D3_TILE, lr, lg);          // A[I,K]^T -= P_K P_I^T
-                else acc[t] = d3_mma<true, false>(acc[t], Pp + I * D3_TILE, K == J ? dinv : Xr + K * D3_TILE, lr, lg);   // X[I,K] -= L[I,J] X[J,K]
+                if (K > J) acc[t] = d3_mma<true, true>(acc[t], P + (K - 1) * D3_TILE, P + (I - 1) * D3_TILE, lr, lg);          // A[I,K]^T -= P_K P_I^T
+                else acc[t] = d3_mma<true, false>(acc[t], P + (I - 1) * D3_TILE, K == J ? dinv : Xr + K * D3_TILE, lr, lg);   // X[I,K] -= L[I,J] X[J,K]
             }
         }
     }
@@ -834,7 +867,7 @@ __device__ __forceinline__ void d3_worker_wave(gfloat* Sb, int64_t ld, gfloat* T
 
 __global__ __launch_bounds__(D3_THREADS, 4) void potrf_diag3_kernel(float* __restrict__ S, int64_t ld, int64_t k0, float* __restrict__ tinv,
                                                                     int* __restrict__ info, int block_index, const BatchMat* __restrict__ mats) {
-    __shared__ float Pp[8 * D3_TILE], Xr[8 * D3_TILE], dinvb[2 * D3_TILE], stage[D3_TILE];
+    __shared__ __attribute__((aligned(16))) float Pp[2 * D3_PBUF], Xr[7 * D3_TILE], dinvb[2 * D3_TILE], stage[16 * D3_SLD];
     if (mats) {                            // batched: workgroup = matrix blockIdx.x of the table (largest first)
         const BatchMat bm = mats[blockIdx.x];
         if (block_index >= bm.mpb) return;
@@ -846,10 +879,10 @@ __global__ __launch_bounds__(D3_THREADS, 4) void potrf_diag3_kernel(float* __res
     const int lr = lane & 15, lg = lane >> 4;
     gfloat* Sb = (gfloat*)(S + k0 * ld + k0);
     gfloat* Tg = (gfloat*)(tinv + (int64_t)block_index * NB * NB);
-    if (w == 0) d3_diagonal_wave(Sb, ld, Tg, Pp, dinvb, stage, info, (int)k0, lane, lr, lg);
-    else if (w == 1) d3_worker_wave<1>(Sb, ld, Tg, Pp, Xr, dinvb, lr, lg);
-    else if (w == 2) d3_worker_wave<2>(Sb, ld, Tg, Pp, Xr, dinvb, lr, lg);
-    else d3_worker_wave<3>(Sb, ld, Tg, Pp, Xr, dinvb, lr, lg);
+    if (w == 0) d3_diagonal_wave(Sb, ld, Pp, dinvb, stage, info, (int)k0, lane, lr, lg);
+    else if (w == 1) d3_worker_wave<1>(Sb, ld, Tg, Pp, Xr, dinvb, stage, lr, lg);
+    else if (w == 2) d3_worker_wave<2>(Sb, ld, Tg, Pp, Xr, dinvb, stage, lr, lg);
+    else d3_worker_wave<3>(Sb, ld, Tg, Pp, Xr, dinvb, stage, lr, lg);
 }
 
 // identity padding of rows m..mp (columns 0..mp)
