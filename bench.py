@@ -461,7 +461,7 @@ def _c4_shard(ctx, args, cases, units, part, lat2, lon2, cap):
     """One rank's shard of the config-4 units as a MonthTileBatch on the lanes of one pool."""
     from oisatgmi import dense
     halo = 3.0 * WORKLOADS[DEFAULT][3]
-    batch = dense.MonthTileBatch(lat2, lon2, 30.0, halo, np.float32, ctx=ctx, streams=int(os.environ.get("OISAT_C4_LANES", "12")))
+    batch = dense.MonthTileBatch(lat2, lon2, 30.0, halo, np.float32, ctx=ctx, streams=12)
     for mth in range(args.c4_months):
         only = [units[i][1] for i in part if units[i][0] == mth]
         if only:

@@ -28,7 +28,6 @@
 // a diagonal block is then a GEMM with the inverse (TRSM as GEMM, the MAGMA trick), so it also
 // runs on MFMA.  The inverses are kept: the triangular solves reuse them.
 #include "oisat_common.h"
-#include <cstring>
 
 #include <algorithm>
 
@@ -1220,10 +1219,7 @@ int potrf_rec_batched(oisat_ctx* h, const ChBatch& bt, int b0, int b1, int* info
                      (int64_t)b0 * NB, (float*)nullptr, info_dev, b0, (const BatchMat*)bt.table_dev);
         return launch_gemm_batched(h, "trsm_gemm", bt, BatchArgs{bt.table_dev, 1, b0, 0, 0}, NB, 1, 0);
     }
-    static const bool pow2 = getenv("OISAT_BATCH_TREE") && !strcmp(getenv("OISAT_BATCH_TREE"), "pow2");
-    int half = 1;
-    while (2 * half < b1 - b0) half *= 2;                  // largest power of two strictly below the node's size
-    const int mid = pow2 ? b0 + half : b0 + (b1 - b0 + 1) / 2;
+    const int mid = b0 + (b1 - b0 + 1) / 2;
     int rc = potrf_rec_batched(h, bt, b0, mid, info_dev);
     if (rc) return rc;
     rc = launch_gemm_batched(h, "syrk_gemm", bt, BatchArgs{bt.table_dev, 0, b0, mid, b1}, (mid - b0) * NB, 0, 1);
