@@ -252,7 +252,8 @@ int oisat_innovation(oisat_ctx* h, int dtype, const void* xb, const int64_t* cel
 int oisat_gemm_nt(oisat_ctx* h, float* C, int64_t ldc, const float* A, int64_t lda, const float* B, int64_t ldb,
                   int64_t M, int64_t N, int64_t K, int mode, int lower);
 
-/* In-place blocked Cholesky S = L L^T (lower; strictly-upper part left untouched), fp32 MFMA
+/* In-place blocked Cholesky S = L L^T: L in the lower triangle; the strictly-upper part is NOT part of the result
+ * (inside the 128x128 diagonal tiles the trailing updates write it; elsewhere it is left untouched), fp32 MFMA
  * trailing updates.  info_host: 0 ok, j>0 = first non-positive pivot column (1-based). */
 int oisat_potrf(oisat_ctx* h, float* S, int64_t m, int64_t ld, int* info_host);
 

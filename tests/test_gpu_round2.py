@@ -672,3 +672,88 @@ def test_config4_units_at_full_size_on_one_gpu(ctx):
             got = slab[batch.offsets[u]: batch.offsets[u] + int(np.prod(shape))].reshape(shape)
             assert np.abs(got[0] - xa[y0:y1, x0:x1]).max() <= tol and np.abs(got[1] - inc[y0:y1, x0:x1]).max() <= tol, (k, ti)
     batch.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m", [1, 15, 16, 17, 127, 128, 129, 300])
+def test_diagonal_block_kernel_edge_sizes_and_every_pivot_position(ctx, m):
+    """potrf_diag3 (the register-resident 128x128 diagonal-block kernel): sizes around its 16-column and 128-column
+    granules (identity padding inside the block), L L^T = S and, through oisat_potrs (which multiplies by the inverted
+    diagonal blocks the kernel leaves), L^-1; then a non-positive pivot planted at every position of a 16-column step
+    and in every 16x16 tile row is reported with its 1-based column and nothing else."""
+    lib = ctx.lib
+    rng = np.random.default_rng(900 + m)
+    A = rng.normal(size=(m, m + 8))
+    S_ref = A @ A.T / (m + 8) + 0.5 * np.eye(m)
+    mp = -(-m // 128) * 128
+    Sp = np.zeros((mp, mp), np.float32)
+    Sp[:m, :m] = S_ref
+    S = ctx.upload(Sp)
+    info = C.c_int(-1)
+    ctx.check(lib.oisat_potrf(ctx.h, S.ptr, m, mp, C.byref(info)))
+    assert info.value == 0
+    full = ctx.download(S.ptr, (mp, mp), np.float32)
+    Lh = np.tril(full[:m, :m]).astype(np.float64)
+    assert np.linalg.norm(Lh @ Lh.T - S_ref) / np.linalg.norm(S_ref) < 5e-7
+    if m <= 128:                                            # one diagonal block: the kernel writes the lower triangle only
+        np.testing.assert_array_equal(np.triu(full[:m, :m], 1), np.triu(Sp[:m, :m], 1))
+    rhs = rng.normal(size=m)
+    zb = ctx.upload(rhs)
+    ctx.check(lib.oisat_potrs(ctx.h, S.ptr, m, mp, zb.ptr))
+    z = ctx.download(zb.ptr, (m,), np.float64)
+    zr = np.linalg.solve(S_ref, rhs)
+    assert np.linalg.norm(z - zr) / np.linalg.norm(zr) < 2e-4
+    if m == 300:
+        for col in list(range(130, 146)) + [0, 16, 47, 127, 128, 255, 256, 299]:
+            bad = Sp.copy()
+            bad[col, col] = -3.0
+            Bb = ctx.upload(bad)
+            with pytest.raises(_hip.OisatError):
+                ctx.check(lib.oisat_potrf(ctx.h, Bb.ptr, m, mp, C.byref(info)))
+            assert info.value == col + 1, (col, info.value)
+            Bb.free()
+        assert ctx.solve_status() == (0, 0, 0)              # checked failures leave nothing sticky behind
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("schedule", ["overlap", "sequential"])
+def test_batch_schedules_give_the_same_fields(ctx, schedule, monkeypatch):
+    """BatchedFactor's two schedules (groups side by side / one after the other; either way the host waits for a group
+    and then enqueues its solves) are the same arithmetic: identical fields, and equal to the lane-serial analysis to
+    refinement accuracy."""
+    monkeypatch.setenv("OISAT_BATCH_SCHEDULE", schedule)
+    p = syn.point_obs_case(72, 144, 3000, 77, swaths=True)
+    ta = dense.TiledAnalysis(p.lat, p.lon, tile_deg=30.0, halo_km=900.0, dtype=np.float32, streams=4)
+    assert ta.batched
+    ta.load(p.Xa, p.Sa, p.obs_lat, p.obs_lon, p.obs_y, p.obs_var)
+    ta.run(300.0, refine=1, check_pd=True)
+    assert ta.factor.schedule == schedule and len(ta.factor.groups) >= 1
+    xa, inc = ta.download()
+    ta.close()
+    tb = dense.TiledAnalysis(p.lat, p.lon, tile_deg=30.0, halo_km=900.0, dtype=np.float32, streams=2, batched=False)
+    tb.load(p.Xa, p.Sa, p.obs_lat, p.obs_lon, p.obs_y, p.obs_var)
+    tb.run(300.0, refine=1, check_pd=True)
+    xb, incb = tb.download()
+    tb.close()
+    assert np.isfinite(xa).all() and np.abs(inc).max() > 0
+    assert np.abs(xa - xb).max() <= 5e-6 * np.abs(p.Xa).max()
+    test_batch_schedules_give_the_same_fields.results = getattr(test_batch_schedules_give_the_same_fields, "results", {})
+    test_batch_schedules_give_the_same_fields.results[schedule] = xa
+    if len(test_batch_schedules_give_the_same_fields.results) == 2:
+        r = test_batch_schedules_give_the_same_fields.results
+        np.testing.assert_array_equal(r["overlap"], r["sequential"])
+
+
+@pytest.mark.gpu
+def test_config4_shard_emulation_leg(ctx):
+    """bench.py --c4-shards: every rank's shard of the W-way partition timed alone on this GPU (one month here)."""
+    import types
+    import bench
+    import torch
+    lat, lon = syn.global_grid(720, 1440)
+    args = types.SimpleNamespace(c4_months=1, c4_passes=1)
+    out = bench.config4_shards_leg(ctx, args, lat, lon, torch.cuda.synchronize, [1, 2])
+    assert set(out) >= {"world_1", "world_2", "workload", "note"}
+    assert len(out["world_2"]["rank_seconds"]) == 2 and sum(out["world_2"]["units_per_rank"]) == out["world_1"]["units_per_rank"][0]
+    assert 1.0 < out["world_2"]["speedup_vs_1"] <= 2.2
+    assert out["world_2"]["speedup_bound_from_load_balance"] > 1.9
