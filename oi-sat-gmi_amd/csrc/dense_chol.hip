@@ -959,8 +959,8 @@ __device__ __forceinline__ bool wait_payload(const double* src, double* vec, Trs
 template <int TRANSPOSE>
 __global__ __launch_bounds__(256) void trsv_pipe_kernel(const float* __restrict__ L, int64_t ld, const float* __restrict__ tinv, int nb,
                                                          const double* __restrict__ rhs, double* __restrict__ sol,
-                                                         TrsvCtl* __restrict__ ctl, unsigned* __restrict__ err_total) {
-    extern __shared__ __attribute__((aligned(16))) float tile[];        // [128][TLD]
+                                                         TrsvCtl* __restrict__ ctl, unsigned* __restrict__ err_total, int two_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];        // [128][TLD]  (+ a second one for T_b if two_tiles)
     __shared__ double vec[NB], part[NB];
     __shared__ unsigned s_ticket, s_ok;
     const int tid = threadIdx.x;
@@ -979,27 +979,36 @@ __global__ __launch_bounds__(256) void trsv_pipe_kernel(const float* __restrict_
     const float* Tb = tinv + (int64_t)b * NB * NB;
     const float* base = TRANSPOSE ? L + (int64_t)(nb - 1) * NB * ld + (int64_t)b * NB : L + (int64_t)b * NB * ld;
     const int64_t hop = TRANSPOSE ? -(int64_t)NB * ld : (int64_t)NB;      // pointer step from one producer's block to the next
-    if (nsteps > 0) { TILE_PREFETCH(base, ld) } else { TILE_PREFETCH(Tb, NB) }
+    // two_tiles (launches of <= one workgroup per CU): T_b goes to a second LDS tile right away -- it depends on nobody --
+    // so that the last pass finds it there instead of loading and staging it behind the last producer's hand-over
+    float* const tileT = tile + NB * TLD;
+    if (two_tiles) {
+        TILE_PREFETCH(Tb, NB)
+        float* tile = tileT;                            // TILE_STORE writes to the `tile` in scope
+        TILE_STORE()
+    }
+    if (nsteps > 0) { TILE_PREFETCH(base, ld) } else if (!two_tiles) { TILE_PREFETCH(Tb, NB) }
     for (int step = 0; step <= nsteps; ++step) {
         const bool last = step == nsteps;               // last pass: multiply by the inverted diagonal block
-        TILE_STORE()                                    // this step's block: in LDS before the wait, off the critical path
+        if (!(last && two_tiles)) TILE_STORE()          // this step's block: in LDS before the wait, off the critical path
         if (!last) {
             const int j = TRANSPOSE ? nb - 1 - step : step;
             if (!wait_payload(sol + (int64_t)j * NB, vec, ctl, err_total, tid, &s_ok)) return;
             if (step + 1 < nsteps) { const float* nx = base + (int64_t)(step + 1) * hop; TILE_PREFETCH(nx, ld) }
-            else { TILE_PREFETCH(Tb, NB) }
+            else if (!two_tiles) { TILE_PREFETCH(Tb, NB) }
         } else {
             if (hf == 0) vec[row] = acc;
             __syncthreads();
         }
         double u = 0.0;
         const int c0 = hf * 64;
+        const float* blk = (last && two_tiles) ? tileT : tile;
         if (!TRANSPOSE) {
 #pragma unroll 8
-            for (int c = c0; c < c0 + 64; ++c) u += (double)tile[row * TLD + c] * vec[c];      // row of the block
+            for (int c = c0; c < c0 + 64; ++c) u += (double)blk[row * TLD + c] * vec[c];       // row of the block
         } else {
 #pragma unroll 8
-            for (int c = c0; c < c0 + 64; ++c) u += (double)tile[c * TLD + row] * vec[c];      // column of the block
+            for (int c = c0; c < c0 + 64; ++c) u += (double)blk[c * TLD + row] * vec[c];       // column of the block
         }
         if (hf == 1) part[row] = u;
         __syncthreads();
@@ -1370,15 +1379,19 @@ int trsv_solve(oisat_ctx* h, const ChFactor& f, double* rhs_pad /* mp, overwritt
     unsigned* err_total = (unsigned*)base;
     char* ctl = base + 16;
     HIP_TRY(hipMemsetAsync(ctl, 0, 2 * ctl_bytes, h->stream));
-    const size_t shm = sizeof(float) * NB * TLD;
+    // a second LDS tile per workgroup (132 KB: one workgroup per CU) when every block row still gets its own CU at once;
+    // larger systems keep two workgroups per CU in flight (they are bound by streaming L, not by the hop latency)
+    static const bool allow_two = !getenv("OISAT_TRSV_TWO_TILES") || atoi(getenv("OISAT_TRSV_TWO_TILES")) != 0;
+    const int two = allow_two && nb <= h->cu_count ? 1 : 0;
+    const size_t shm = sizeof(float) * NB * TLD * (two ? 2 : 1);
     // forward: L y = rhs   (y -> tmp, pre-filled with the "not yet published" pattern)
     HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)tmp, (int)kTrsvFill32, (size_t)f.mp * 2, h->stream));
     OISAT_LAUNCH(h, "trsv_fwd", (trsv_pipe_kernel<0>), dim3(nb), dim3(256), shm, f.S, f.ld, (const float*)f.tinv, nb,
-                 (const double*)rhs_pad, tmp, (TrsvCtl*)ctl, err_total);
+                 (const double*)rhs_pad, tmp, (TrsvCtl*)ctl, err_total, two);
     // backward: L^T z = y  (z -> rhs_pad; the forward sweep has consumed it by now, stream order)
     HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)rhs_pad, (int)kTrsvFill32, (size_t)f.mp * 2, h->stream));
     OISAT_LAUNCH(h, "trsv_bwd", (trsv_pipe_kernel<1>), dim3(nb), dim3(256), shm, f.S, f.ld, (const float*)f.tinv, nb,
-                 (const double*)tmp, rhs_pad, (TrsvCtl*)(ctl + ctl_bytes), err_total);
+                 (const double*)tmp, rhs_pad, (TrsvCtl*)(ctl + ctl_bytes), err_total, two);
     return OISAT_OK;
 }
 
@@ -1402,10 +1415,10 @@ int trsm_rows_rec(oisat_ctx* h, const ChFactor& f, float* X, int64_t nrows, int6
 hipError_t dense_kernel_attributes() {
     static const hipError_t attr_rc = []() {
         hipError_t e = hipFuncSetAttribute((const void*)trsv_pipe_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)(sizeof(float) * NB * TLD));
+                                    (int)(sizeof(float) * NB * TLD * 2));
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)trsv_pipe_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)(sizeof(float) * NB * TLD));
+                                    (int)(sizeof(float) * NB * TLD * 2));
         return e;
     }();
     return attr_rc;
