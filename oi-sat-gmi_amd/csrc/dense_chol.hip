@@ -1298,7 +1298,8 @@ int potrf_lookahead(oisat_ctx* h, float* S, int64_t ld, int64_t nb, float* tinv,
         const char* pe = getenv("OISAT_AUX_PRIORITY");
         const int prio = pe ? atoi(pe) : prio_low;
         // OISAT_AUX_FREE_CUS=k: keep the first k CUs (bits of the queue's CU mask) off limits for the bulk updates, so
-        // that the panel chain's one-workgroup kernels (137 KB of LDS: a whole CU) always find a home
+        // that the panel chain's one-workgroup kernels always find a home (round 1, when the diagonal kernel needed
+        // 137 KB of LDS = a whole CU; every masked GEMM loses >= 12 %)
         const char* fe = getenv("OISAT_AUX_FREE_CUS");
         const int nfree = fe ? atoi(fe) : 0;
         if (nfree > 0 && nfree < h->cu_count) {
@@ -1451,11 +1452,10 @@ extern "C" int oisat_potrf(oisat_ctx* h, float* S, int64_t m, int64_t ld, int* i
         OISAT_LAUNCH(h, "pad_identity", pad_identity_kernel, dim3(stream_grid((mp - m) * mp, 256)), dim3(256), 0, S, ld, m, mp);
     }
     // schedule: recursive by default.  The two-stream look-ahead schedule (OISAT_POTRF=lookahead[:panel blocks]) is
-    // kept selectable: measured at m = 1e4 it only ties the recursive one (12.7 ms per analysis either way).  The
-    // rocprofv3 timeline shows why: the first potrf_diag after a bulk update is dispatched at once but runs 300-350 us
-    // instead of 34 -- its workgroup needs 137 KB of LDS, a CU holding even one 74 KB gemm_nt workgroup cannot take
-    // it, and freed slots are refilled by the bulk launch until that launch drains; stream priority does not change
-    // this (nothing is preempted, and the slot that frees is never big enough).  See DESIGN.md section 4.
+    // kept selectable: at m = 1e4 it ties the recursive one in every round (round 1: 12.7 ms per analysis either way,
+    // the 137 KB diagonal kernel waiting 300-350 us for an empty CU under the bulk updates; round 2 with the 26 KB
+    // register-resident kernel: 7.75-7.80 ms at panel widths 6..20 against 7.84 ms) -- its rank-256..1024 bulk updates
+    // cost 5.4-6.3 ms where the recursion's GEMMs cost 4.1.  See DESIGN.md section 4.
     bool lookahead = false;
     int64_t pw = 4;
     if (const char* env = getenv("OISAT_POTRF")) {
