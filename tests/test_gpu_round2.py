@@ -757,3 +757,54 @@ def test_config4_shard_emulation_leg(ctx):
     assert len(out["world_2"]["rank_seconds"]) == 2 and sum(out["world_2"]["units_per_rank"]) == out["world_1"]["units_per_rank"][0]
     assert 1.0 < out["world_2"]["speedup_vs_1"] <= 2.2
     assert out["world_2"]["speedup_bound_from_load_balance"] > 1.9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("itype", [4, 2, 1])
+def test_interpolator_full_size_granule_against_oracle(ctx, itype):
+    """SURVEY 8a rows a7-a9 at the BASELINE grid size: one OMI-like granule (1644 x 60 = 98 640 pixels, quality-flag
+    holes) onto the 0.25 deg global grid (720 x 1440 = 1 036 800 targets), every field of the record against the
+    oracle's restatement of interpolator.py:100-291 -- bit-for-bit for the nearest-neighbour types (the same pixel is
+    picked), to rounding for the Delaunay type (same triangulation: qhull on both sides, same barycentric order)."""
+    g = syn.swath_granule(7007, nscan=1644, npix=60, lat0=-70.0, lat1=70.0, lon_c=20.0, width_deg=24.0)
+    ctm = syn.regional_ctm_grid(-89.875, 89.875, -179.875, 179.875, 0.25, 0.25)
+    r = interpolator(itype, 0.25, g, ctm, 0.75)
+    o = orc.interpolator(itype, 0.25, g, ctm, 0.75, record_type=cfg.satellite_amf)
+    assert r.vcd.shape == (720, 1440) and np.isfinite(r.vcd).sum() > 50000
+    for name in ("vcd", "amf", "uncertainty"):
+        a, b = np.asarray(getattr(r, name)), np.asarray(getattr(o, name))
+        assert np.array_equal(np.isnan(a), np.isnan(b)), name
+        if itype == 1:
+            np.testing.assert_allclose(a, b, rtol=1e-11, atol=1e-13 * np.nanmax(np.abs(b)), equal_nan=True, err_msg=name)
+        else:
+            np.testing.assert_array_equal(a, b, err_msg=name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("res", [2.5, 2.0])
+def test_upscaler_full_size_against_oracle(ctx, res):
+    """SURVEY 8a row a7 at the BASELINE grid size class: a 0.25 deg global field with NaN holes, on the fine grid that
+    interpolator() builds from the model grid (np.arange from the model's first centre, interpolator.py:141-143: the
+    model centres ARE fine nodes), box-filtered and resampled onto a 2.5 deg (10 x 10 window) and a 2.0 deg (8 x 8) model
+    grid, mean and variance kernels, against the oracle's restatement of interpolator.py:48-97 (convolve2d 'symm' + k-d
+    tree pick).  (With both grids cell-centred every model centre would sit exactly midway between four fine nodes; which
+    of those exact ties scipy's k-d tree returns is its traversal order -- parity unpinned for that configuration, which
+    the reference's own grid construction never produces.)"""
+    from oisatgmi.interpolator import _upscaler
+    ctm = syn.regional_ctm_grid(-90 + res / 2, 90 - res / 2, -180 + res / 2, 180 - res / 2, res, res)
+    clat, clon = ctm["Latitude"], ctm["Longitude"]
+    lat = np.arange(clat.min(), clat.max() + 0.25, 0.25)           # interpolator.py:141-143
+    lon = np.arange(clon.min(), clon.max() + 0.25, 0.25)
+    X, Y = np.meshgrid(lon, lat)
+    assert X.shape[0] > 700 and X.shape[1] > 1400
+    rng = np.random.default_rng(int(res * 10))
+    Z = rng.lognormal(size=X.shape)
+    Z[rng.uniform(size=Z.shape) < 0.01] = np.nan
+    thr = np.sqrt(2.0) * res
+    for err in (False, True):
+        ox, oy, oz, need = _upscaler(X, Y, Z.copy(), ctm, 0.25, thr, error=err)
+        rx, ry, rz, rneed = orc.upscaler(X, Y, Z.copy(), ctm, 0.25, thr, error=err)
+        assert bool(need) == bool(rneed) and oz.shape == clat.shape
+        assert np.array_equal(np.isnan(oz), np.isnan(rz))
+        np.testing.assert_allclose(oz, rz, rtol=1e-12, equal_nan=True)
+        np.testing.assert_array_equal(ox, rx)
