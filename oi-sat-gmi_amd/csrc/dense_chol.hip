@@ -50,6 +50,8 @@ struct BatchArgs {
     const BatchMat* mats;        // nullptr: not a batched launch
     int kind;                    // 0: trailing update of node (b0, mid, b1);  1: TRSM of the panel below diagonal block b0
     int b0, mid, b1;
+    const int* cum = nullptr;    // persistent kernel: prefix sums of the members' tile counts at this node (cum[cnt] = total):
+    int cnt = 0, total = 0;      // virtual ids 0 .. total-1 are exactly the real tiles, member = the w with cum[w] <= id < cum[w+1]
 };
 
 // operands of matrix `which` for this node, in units of `unit` rows/columns (128 or 64); false: the node does not apply
@@ -265,7 +267,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(float* C0, int64_t ldc0
     const int lane = t & 63, wid = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wr = wid >> 1, wc = wid & 1;
     // virtual tile ids: plain launch: the tiles of C;  batched launch: (ntm0 = tiles of the largest matrix) x (ntn0 = matrices)
-    const int64_t VT = BATCH ? (int64_t)ntm0 * ntn0 : (int64_t)ntiles_total;
+    const bool compact = BATCH && ba.cum != nullptr;
+    const int64_t VT = compact ? (int64_t)ba.total : (BATCH ? (int64_t)ntm0 * ntn0 : (int64_t)ntiles_total);
+    int cw = 0;                                             // compact enumeration: member of the last id located (ids only grow)
     const int64_t G = gridDim.x;                            // a multiple of 8 whenever a workgroup gets more than one tile
     // LDS-DMA (global_load_lds_dwordx4): wave `wid` brings rows wid*32 + 8i .. +7 (i = 0..3) of each operand, one KiB
     // per instruction, straight into LDS -- no staging registers, no ds_write, and the wave only waits for its pieces
@@ -293,8 +297,21 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(float* C0, int64_t ldc0
             int64_t lda = lda0, ldb = ldb0, ldc = ldc0;
             int ntm = ntm0, ntn = ntn0, wg = (int)lin;
             if (BATCH) {
-                const int which = (int)(lin / ntm0);
-                wg = (int)(lin - (int64_t)which * ntm0);
+                int which;
+                if (compact) {                              // ids of a workgroup only grow: gallop forward from the last member,
+                    int lo = cw, step = 1;                  // then bisect (wave-uniform: scalar loads)
+                    while (lo + step < ba.cnt && ba.cum[lo + step] <= (int)lin) { lo += step; step <<= 1; }
+                    int hi = lo + step < ba.cnt ? lo + step : ba.cnt;
+                    while (hi - lo > 1) {
+                        const int md = (lo + hi) >> 1;
+                        if (ba.cum[md] <= (int)lin) lo = md; else hi = md;
+                    }
+                    cw = which = lo;
+                    wg = (int)lin - ba.cum[lo];
+                } else {
+                    which = (int)(lin / ntm0);
+                    wg = (int)(lin - (int64_t)which * ntm0);
+                }
                 if (!batch_operands(ba, which, NB, C, ldc, A, lda, B, ldb, ntm, ntn)) continue;
             }
             int ti = 0, tj = 0, rem = wg;
@@ -1173,6 +1190,63 @@ int launch_gemm(oisat_ctx* h, const char* name, float* C, int64_t ldc, const flo
 // matrices that reach it (a prefix of the table), every launch covers all of them ------------------------------------------
 static inline int64_t tiles_lower(int64_t ntm, int64_t ntn) { return ntn * ntm - ntn * (ntn - 1) / 2; }
 
+// node key of the compact-enumeration tables: kind 0 (b0, mid, b1) / kind 1 (b0)
+static inline long long cum_key_of(int kind, int b0, int mid, int b1) {
+    return ((long long)kind << 60) | ((long long)b0 << 40) | ((long long)mid << 20) | (long long)b1;
+}
+
+// prefix sums of the members' 128x128 tile counts for every node of the recursion tree (the tree of potrf_rec_batched)
+static void build_cum_tables(ChBatch* bt, std::vector<int>& host) {
+    std::vector<std::pair<long long, int>> keys;            // (key, slot)
+    auto add = [&](int kind, int b0, int mid, int b1) {
+        const int off = (int)host.size();
+        int acc = 0, cnt = 0;
+        host.push_back(0);
+        for (const BatchMat& m : bt->table) {
+            int64_t rows, cols;
+            if (kind == 0) { rows = m.mpb - mid; cols = (b1 < m.mpb ? b1 : m.mpb) - mid; }
+            else { rows = m.mpb - b0 - 1; cols = 1; }
+            if (rows <= 0 || cols <= 0) break;
+            acc += (int)(kind == 0 ? cols * rows - cols * (cols - 1) / 2 : rows);
+            host.push_back(acc);
+            ++cnt;
+        }
+        if (cnt == 0) { host.resize(off); return; }
+        keys.emplace_back(cum_key_of(kind, b0, mid, b1), (int)bt->cum_off.size());
+        bt->cum_off.push_back(off);
+        bt->cum_cnt.push_back(cnt);
+        bt->cum_total.push_back(acc);
+    };
+    struct Rec {
+        static void go(int b0, int b1, const decltype(add)& add) {
+            if (b1 - b0 == 1) { add(1, b0, 0, 0); return; }
+            const int mid = b0 + (b1 - b0 + 1) / 2;
+            go(b0, mid, add);
+            add(0, b0, mid, b1);
+            go(mid, b1, add);
+        }
+    };
+    Rec::go(0, bt->max_mpb, add);
+    std::sort(keys.begin(), keys.end());
+    std::vector<int> off, cnt, tot;
+    for (auto& kv : keys) {
+        bt->cum_key.push_back(kv.first);
+        off.push_back(bt->cum_off[kv.second]); cnt.push_back(bt->cum_cnt[kv.second]); tot.push_back(bt->cum_total[kv.second]);
+    }
+    bt->cum_off = off; bt->cum_cnt = cnt; bt->cum_total = tot;
+}
+
+static inline void attach_cum(const ChBatch& bt, BatchArgs& ba) {
+    if (!bt.cum_dev) return;
+    const long long key = cum_key_of(ba.kind, ba.b0, ba.kind == 0 ? ba.mid : 0, ba.kind == 0 ? ba.b1 : 0);
+    auto it = std::lower_bound(bt.cum_key.begin(), bt.cum_key.end(), key);
+    if (it == bt.cum_key.end() || *it != key) return;
+    const size_t s = it - bt.cum_key.begin();
+    ba.cum = bt.cum_dev + bt.cum_off[s];
+    ba.cnt = bt.cum_cnt[s];
+    ba.total = bt.cum_total[s];
+}
+
 int launch_gemm_batched(oisat_ctx* h, const char* name, const ChBatch& bt, BatchArgs ba, int K, int mode, int lower) {
     // participants and tile counts (units of 128) from the host copy of the table
     int cnt = 0;
@@ -1196,8 +1270,10 @@ int launch_gemm_batched(oisat_ctx* h, const char* name, const ChBatch& bt, Batch
             OISAT_LAUNCH(h, name, gemm_nt_rows64_kernel<true>, dim3((unsigned)(rows * 2), (unsigned)cnt), dim3(256), 0, (float*)nullptr,
                          (int64_t)0, (const float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0, K, mode, ba);
         } else {
-            OISAT_LAUNCH(h, name, gemm_nt_kernel<true>, dim3(persistent_grid(h, rows * cnt)), dim3(256), 0, (float*)nullptr, (int64_t)0,
-                         (const float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0, (int)rows, cnt, K, mode, 0, 0, ba);
+            attach_cum(bt, ba);
+            OISAT_LAUNCH(h, name, gemm_nt_kernel<true>, dim3(persistent_grid(h, ba.cum ? ba.total : rows * cnt)), dim3(256), 0,
+                         (float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0, (int)rows, cnt, K,
+                         mode, 0, 0, ba);
         }
         return OISAT_OK;
     }
@@ -1210,8 +1286,9 @@ int launch_gemm_batched(oisat_ctx* h, const char* name, const ChBatch& bt, Batch
         OISAT_LAUNCH(h, name, gemm_nt_big_kernel<true>, dim3((unsigned)mx, (unsigned)cnt), dim3(256), 0, (float*)nullptr, (int64_t)0,
                      (const float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0, 0, 0, K, mode, lower, 0, ba);
     } else {
-        OISAT_LAUNCH(h, name, gemm_nt_kernel<true>, dim3(persistent_grid(h, mx * cnt)), dim3(256), 0, (float*)nullptr, (int64_t)0,
-                     (const float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0, (int)mx, cnt, K, mode, lower, 0, ba);
+        if (lower) attach_cum(bt, ba);                          // (the tables hold the lower-triangle tile counts)
+        OISAT_LAUNCH(h, name, gemm_nt_kernel<true>, dim3(persistent_grid(h, ba.cum ? ba.total : mx * cnt)), dim3(256), 0, (float*)nullptr,
+                     (int64_t)0, (const float*)nullptr, (int64_t)0, (const float*)nullptr, (int64_t)0, (int)mx, cnt, K, mode, lower, 0, ba);
     }
     return OISAT_OK;
 }
@@ -1685,6 +1762,18 @@ extern "C" int oisat_batch_create(oisat_ctx* h, int nmat, float* const* S, const
         oisat_set_error("oisat_batch_create: upload of the table failed");
         return OISAT_EHIP;
     }
+    {
+        std::vector<int> host;
+        build_cum_tables(bt, host);
+        if (hipMalloc(&bt->cum_dev, sizeof(int) * host.size()) != hipSuccess ||
+            hipMemcpy(bt->cum_dev, host.data(), sizeof(int) * host.size(), hipMemcpyHostToDevice) != hipSuccess) {
+            if (bt->cum_dev) (void)hipFree(bt->cum_dev);
+            (void)hipFree(bt->table_dev);
+            delete bt;
+            oisat_set_error("oisat_batch_create: tile-enumeration tables failed");
+            return OISAT_ENOMEM;
+        }
+    }
     int id = -1;
     for (size_t i = 0; i < h->batches.size(); ++i)
         if (!h->batches[i]) { id = (int)i; break; }
@@ -1699,6 +1788,7 @@ extern "C" int oisat_batch_destroy(oisat_ctx* h, int batch_id) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     ChBatch* bt = h->batches[batch_id];
     if (bt->table_dev) HIP_TRY(hipFree(bt->table_dev));
+    if (bt->cum_dev) HIP_TRY(hipFree(bt->cum_dev));
     delete bt;
     h->batches[batch_id] = nullptr;
     return OISAT_OK;

@@ -45,6 +45,11 @@ struct BatchMat {                // one matrix of a batched factorization (devic
 
 struct ChBatch {                 // matrices factored in lock-step by oisat_batch_potrf (sorted by block count, largest first)
     BatchMat* table_dev = nullptr;
+    // compact tile enumeration of the persistent GEMM launches: for every node of the recursion tree the prefix sums of
+    // the members' tile counts (cum[0] = 0 .. cum[cnt] = total), built once by oisat_batch_create
+    int* cum_dev = nullptr;
+    std::vector<int> cum_off, cum_cnt, cum_total;      // per node slot (see ChBatch::slot)
+    std::vector<long long> cum_key;                     // node key -> slot (sorted, binary search)
     std::vector<BatchMat> table;
     std::vector<int> order;      // table[i] is the caller's matrix order[i]
     int max_mpb = 0;

@@ -61,6 +61,7 @@ extern "C" void oisat_shutdown(oisat_ctx* h) {
     for (auto* b : h->batches)
         if (b) {
             if (b->table_dev) (void)hipFree(b->table_dev);
+            if (b->cum_dev) (void)hipFree(b->cum_dev);
             delete b;
         }
     delete h;
