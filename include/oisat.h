@@ -176,11 +176,24 @@ int oisat_boxfilter_symm(oisat_ctx* h, int dtype, const void* Z, int64_t Ny, int
 /* Bounded-radius exact nearest neighbour (what cKDTree.query + the `dists > 2*threshold` mask
  * need, interpolator.py:145-150,:78-91,:28-33).  Points/targets: dev double lon/lat arrays.
  * idx_out: dev int32[T], -1 where no point lies within max_dist (those cells are NaN-masked by
- * the caller's gather).  Ties resolve to the lowest point index.  Distances are Euclidean in
+ * the caller's gather).  Exact ties resolve to the lowest point index (see oisat_nn_query_ties).  Distances are Euclidean in
  * degree space in double, like the reference.  Synchronises internally (sizes a workspace). */
 int oisat_nn_query(oisat_ctx* h, const double* plon, const double* plat, int64_t P,
                    const double* tlon, const double* tlat, int64_t T, double max_dist,
                    int32_t* idx_out, double* dist_out /* may be NULL */);
+
+/* Same search, and additionally reports the targets whose nearest point is NOT unique: tie_list (dev int32[T])
+ * receives, in no particular order, the ids of the kept targets for which a second point lies at the same distance
+ * (to within 8 ulp of the squared distance); *n_ties (host) = how many.  Where the minimum is unique it is what
+ * cKDTree(points).query(xi) returns (interpolator.py:82-88); where it is not, the reference's answer is whichever
+ * of the equidistant nodes scipy's tree traversal meets first, so the host side re-queries exactly the listed
+ * targets against that tree and patches idx_out (oisatgmi/interpolator.py: NNIndex.query_device).  This happens on
+ * the reference's own MOPITT / GOSAT settings: grid_size 1.0 (reader.py:1209,:1271) against a model longitude
+ * spacing of 1.25 or 2.5 degrees puts every other model centre midway between two fine-grid nodes. */
+int oisat_nn_query_ties(oisat_ctx* h, const double* plon, const double* plat, int64_t P,
+                        const double* tlon, const double* tlat, int64_t T, double max_dist,
+                        int32_t* idx_out, double* dist_out /* may be NULL */,
+                        int32_t* tie_list, int64_t* n_ties);
 
 /* out[f][t] = idx[t] >= 0 ? values[f][idx[t]] : NaN  for nfields stacked fields
  * (the `Z.ravel()[idx]` + mask of _interpolosis type 2/4, interpolator.py:17-20,:28-33). */
@@ -201,6 +214,27 @@ int oisat_linear_interp(oisat_ctx* h, int dtype, const double* tlon, const doubl
                         const int32_t* nn_idx, const int32_t* vertex_to_simplex, const int32_t* simplices,
                         const int32_t* neighbors, const double* transform, int64_t nsimplex,
                         const void* values, int64_t P, int nfields, void* out, const double* bounds_host);
+
+/* Targets whose location in the triangulation is NOT unique: amb_list (dev int32[T], no particular order) receives the
+ * ids of the targets for which a second simplex accepts the point as well (it lies on a shared facet or vertex to within
+ * scipy's eps) or whose walk had to fall back to the brute-force scan; *n_amb (host) = how many.  scipy evaluates targets
+ * sequentially and starts every walk where the previous one ended (LinearNDInterpolator -> qhull._find_simplex with a
+ * carried `start`), so for such targets the simplex -- and, next to a NaN vertex, the NaN pattern of interpolator.py:12-16 --
+ * depends on the order of evaluation.  The normal case for level-3 lattice products (MOPITT, reader.py:1150-1211: every
+ * fine node on the diagonal of a lattice square).  The host locates the listed targets with the same sequential search
+ * (Delaunay.find_simplex over the whole target list) and passes the result to oisat_linear_interp_forced. */
+int oisat_linear_locate(oisat_ctx* h, const double* tlon, const double* tlat, int64_t T, const int32_t* nn_idx,
+                        const int32_t* vertex_to_simplex, const int32_t* simplices, const int32_t* neighbors,
+                        const double* transform, int64_t nsimplex, int64_t P, const double* bounds_host,
+                        int32_t* amb_list, int64_t* n_amb);
+
+/* oisat_linear_interp with per-target simplices from the host: forced dev int32[T]; -2 = locate on the device (walk),
+ * -1 = outside the triangulation (NaN), >= 0 = evaluate in that simplex. */
+int oisat_linear_interp_forced(oisat_ctx* h, int dtype, const double* tlon, const double* tlat, int64_t T,
+                               const int32_t* nn_idx, const int32_t* vertex_to_simplex, const int32_t* simplices,
+                               const int32_t* neighbors, const double* transform, int64_t nsimplex,
+                               const void* values, int64_t P, int nfields, void* out, const double* bounds_host,
+                               const int32_t* forced);
 
 /* RBFInterpolator(points, values, neighbors=5)(targets) for nfields stacked fields (_interpolosis type 3,
  * interpolator.py:21-27): thin-plate-spline kernel, degree-1 polynomial tail, no smoothing; per target the

@@ -7,8 +7,12 @@
 // whose cell edge equals the mask radius: only neighbours within `max_dist` can survive the mask,
 // so the 3x3 cell block around a target contains every candidate and the search is exact.  The
 // resulting index vector is reused by every field (one gather kernel for a whole stack of fields).
-// Distances are Euclidean in degree space, in double, exactly like the reference; ties go to the
-// lowest point index (cKDTree's tie order is unspecified).
+// Distances are Euclidean in degree space, in double, exactly like the reference.  Exactly equidistant
+// points DO occur on the reference's own settings (grid_size 1.0 against a 1.25 / 2.5 deg model longitude
+// spacing puts every other model centre midway between two fine nodes); there the reference returns
+// whichever node scipy's k-d tree meets first.  The kernel reports such targets (oisat_nn_query_ties) and
+// the host resolves just those with the same tree the reference builds; everywhere else the minimum is
+// unique and the lowest-index rule below never decides anything.
 #include "oisat_common.h"
 
 namespace {
@@ -164,15 +168,18 @@ __global__ __launch_bounds__(256) void nn_scatter_kernel(const int32_t* __restri
     }
 }
 
+// Exact ties: when a second point lies at the same distance (to within a few ulp) the target's id is appended to
+// `tie_list`; the caller resolves those targets with the reference's own tree (see oisat_nn_query_ties).
 __global__ __launch_bounds__(256) void nn_query_kernel(const double* __restrict__ px, const double* __restrict__ py,
                                                         const double* __restrict__ tx, const double* __restrict__ ty, int64_t Tn,
                                                         HashGrid g, const unsigned* __restrict__ start,
                                                         const int32_t* __restrict__ sorted, double max_dist,
-                                                        int32_t* __restrict__ idx_out, double* __restrict__ dist_out) {
+                                                        int32_t* __restrict__ idx_out, double* __restrict__ dist_out,
+                                                        int32_t* __restrict__ tie_list, unsigned* __restrict__ tie_count) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < Tn; t += stride) {
         const double x = tx[t], y = ty[t];
-        double best = __builtin_inf();
+        double best = __builtin_inf(), second = __builtin_inf();
         int32_t bi = -1;
         if (x == x && y == y) {
             int cx, cy;
@@ -186,7 +193,8 @@ __global__ __launch_bounds__(256) void nn_query_kernel(const double* __restrict_
                         const int32_t i = sorted[s];
                         const double dx = px[i] - x, dy = py[i] - y;
                         const double d2 = dx * dx + dy * dy;
-                        if (d2 < best || (d2 == best && i < bi)) { best = d2; bi = i; }
+                        if (d2 < best || (d2 == best && i < bi)) { second = best; best = d2; bi = i; }
+                        else if (d2 < second) second = d2;
                     }
                 }
             }
@@ -195,6 +203,7 @@ __global__ __launch_bounds__(256) void nn_query_kernel(const double* __restrict_
         const bool keep = bi >= 0 && !(d > max_dist);          // mask is `dists > 2*threshold`
         idx_out[t] = keep ? bi : -1;
         if (dist_out) dist_out[t] = keep ? d : __builtin_inf();
+        if (tie_list && keep && second - best <= best * 1.8e-15) tie_list[atomicAdd(tie_count, 1u)] = (int32_t)t;
     }
 }
 
@@ -249,20 +258,48 @@ __device__ inline int32_t find_simplex_bruteforce(double x, double y, const int3
     return -1;
 }
 
+// Ambiguous locations.  scipy evaluates the targets one after the other and starts each walk at the simplex the previous
+// target ended in, so a target that lies ON a shared facet or vertex (within eps) gets whichever of the simplices that
+// accept it the walk from the previous target meets first.  The value is the same from either side -- unless the third
+// vertex carries NaN, and then the NaN pattern of the output depends on it.  This is the normal case for level-3 lattice
+// products (MOPITT MOP03: every fine node sits on the diagonal of a lattice square).  The kernel therefore reports the
+// targets for which a second simplex also accepts the point (`amb_list`); the host locates exactly those with scipy's own
+// sequential search over the same triangulation and hands the simplices back through `forced` (-2: not forced, walk;
+// -1: outside; >= 0: that simplex).
+__device__ __forceinline__ bool simplex_accepts(const double* __restrict__ tr, double x, double y, double eps) {
+    if (tr[0] != tr[0]) return true;                                   // degenerate neighbour: let scipy decide
+    const double dx = x - tr[4], dy = y - tr[5];
+    const double b0 = tr[0] * dx + tr[1] * dy, b1 = tr[2] * dx + tr[3] * dy, b2 = 1.0 - b0 - b1;
+    return b0 >= -eps && b0 <= 1.0 + eps && b1 >= -eps && b1 <= 1.0 + eps && b2 >= -eps && b2 <= 1.0 + eps;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void linear_interp_kernel(const double* __restrict__ tx, const double* __restrict__ ty, int64_t Tn,
                                                              const int32_t* __restrict__ nn_idx, const int32_t* __restrict__ v2s,
                                                              const int32_t* __restrict__ simplices, const int32_t* __restrict__ neighbors,
                                                              const double* __restrict__ transform, int32_t ns, const T* __restrict__ values,
-                                                             int64_t P, int nfields, T* __restrict__ out, TriBounds bb) {
+                                                             int64_t P, int nfields, T* __restrict__ out, TriBounds bb,
+                                                             const int32_t* __restrict__ forced, int32_t* __restrict__ amb_list,
+                                                             unsigned* __restrict__ amb_count) {
     const double eps = 100.0 * 2.220446049250313e-16;              // scipy: eps = 100 * DBL_EPSILON
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < Tn; t += stride) {
         const int32_t nn = nn_idx[t];
         int32_t is = -1;
         double c0 = 0.0, c1 = 0.0, c2 = 0.0;
-        if (nn >= 0) {
+        const int32_t f = forced ? forced[t] : -2;
+        if (nn >= 0 && f >= -1) {                                   // located by scipy's sequential search
+            is = f < ns ? f : -1;
+            if (is >= 0) {
+                const double* tr = transform + (int64_t)is * 6;
+                const double dx = tx[t] - tr[4], dy = ty[t] - tr[5];
+                c0 = tr[0] * dx + tr[1] * dy;
+                c1 = tr[2] * dx + tr[3] * dy;
+                c2 = 1.0 - c0 - c1;
+            }
+        } else if (nn >= 0) {
             const double x = tx[t], y = ty[t];
+            bool amb = false;
             is = v2s[nn];
             if (is < 0 || is >= ns) is = 0;
             const int max_hops = 1 + ns / 4;
@@ -288,23 +325,38 @@ __global__ __launch_bounds__(256) void linear_interp_kernel(const double* __rest
                 if (go == -1) { is = -1; break; }                      // left the hull: NaN, no second look (scipy: return -1)
                 if (go == -3) {                                        // degenerate simplex in the way: brute force
                     is = find_simplex_bruteforce(x, y, neighbors, transform, ns, bb, eps, c0, c1, c2);
+                    amb = true;
                     break;
                 }
                 is = go;
             }
-            if (hop >= max_hops) is = find_simplex_bruteforce(x, y, neighbors, transform, ns, bb, eps, c0, c1, c2);   // no convergence
+            if (hop >= max_hops) {                                     // no convergence
+                is = find_simplex_bruteforce(x, y, neighbors, transform, ns, bb, eps, c0, c1, c2);
+                amb = true;
+            }
+            if (amb_list) {
+                if (is >= 0 && !amb) {                                 // does the simplex across a near facet accept it too?
+                    const double c[3] = {c0, c1, c2};
+                    for (int k = 0; k < 3; ++k) {
+                        if (c[k] > 1e-6) continue;
+                        const int32_t nb = neighbors[(int64_t)is * 3 + k];
+                        if (nb >= 0 && simplex_accepts(transform + (int64_t)nb * 6, x, y, eps)) amb = true;
+                    }
+                }
+                if (amb) amb_list[atomicAdd(amb_count, 1u)] = (int32_t)t;
+            }
         }
         if (is < 0) {
-            for (int f = 0; f < nfields; ++f) out[(int64_t)f * Tn + t] = nan_of<T>();
+            for (int f2 = 0; f2 < nfields; ++f2) out[(int64_t)f2 * Tn + t] = nan_of<T>();
         } else {
             const int32_t v0 = simplices[(int64_t)is * 3], v1 = simplices[(int64_t)is * 3 + 1], v2 = simplices[(int64_t)is * 3 + 2];
-            for (int f = 0; f < nfields; ++f) {
-                const T* vf = values + (int64_t)f * P;
+            for (int f2 = 0; f2 < nfields; ++f2) {
+                const T* vf = values + (int64_t)f2 * P;
                 double o = 0.0;
                 o += c0 * (double)vf[v0];
                 o += c1 * (double)vf[v1];
                 o += c2 * (double)vf[v2];
-                out[(int64_t)f * Tn + t] = (T)o;
+                out[(int64_t)f2 * Tn + t] = (T)o;
             }
         }
     }
@@ -665,19 +717,44 @@ static int build_hash(oisat_ctx* h, const double* plon, const double* plat, int6
     return OISAT_OK;
 }
 
-extern "C" int oisat_nn_query(oisat_ctx* h, const double* plon, const double* plat, int64_t P, const double* tlon,
-                              const double* tlat, int64_t Tn, double max_dist, int32_t* idx_out, double* dist_out) {
+static int nn_query_impl(oisat_ctx* h, const double* plon, const double* plat, int64_t P, const double* tlon, const double* tlat,
+                         int64_t Tn, double max_dist, int32_t* idx_out, double* dist_out, int32_t* tie_list, int64_t* n_ties) {
     ARG_CHECK(h && plon && plat && tlon && tlat && idx_out);
-    ARG_CHECK(P > 0 && P < (int64_t)INT32_MAX && Tn > 0 && max_dist > 0.0 && std::isfinite(max_dist));
+    ARG_CHECK(P > 0 && P < (int64_t)INT32_MAX && Tn > 0 && Tn < (int64_t)INT32_MAX && max_dist > 0.0 && std::isfinite(max_dist));
     // cell edge = mask radius: the 3x3 block around a target holds every candidate that can survive the mask
     HashGrid g;
     const unsigned* start;
     const int32_t* sorted;
     const int rc = build_hash(h, plon, plat, P, max_dist, &g, &start, &sorted);
     if (rc != OISAT_OK) return rc;
+    unsigned* count = nullptr;
+    unsigned* count_host = nullptr;
+    if (tie_list) {
+        count = (unsigned*)oisat_ws(h, 1, 64);
+        count_host = (unsigned*)oisat_pinned(h, 64);
+        if (!count || !count_host) return OISAT_ENOMEM;
+        HIP_TRY(hipMemsetAsync(count, 0, 64, h->stream));
+    }
     OISAT_LAUNCH(h, "nn_query", nn_query_kernel, dim3(stream_grid(Tn, 256)), dim3(256), 0, plon, plat, tlon, tlat, Tn, g, start,
-                 sorted, max_dist, idx_out, dist_out);
+                 sorted, max_dist, idx_out, dist_out, tie_list, count);
+    if (tie_list) {
+        HIP_TRY(hipMemcpyAsync(count_host, count, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        *n_ties = (int64_t)count_host[0];
+    }
     return OISAT_OK;
+}
+
+extern "C" int oisat_nn_query(oisat_ctx* h, const double* plon, const double* plat, int64_t P, const double* tlon,
+                              const double* tlat, int64_t Tn, double max_dist, int32_t* idx_out, double* dist_out) {
+    return nn_query_impl(h, plon, plat, P, tlon, tlat, Tn, max_dist, idx_out, dist_out, nullptr, nullptr);
+}
+
+extern "C" int oisat_nn_query_ties(oisat_ctx* h, const double* plon, const double* plat, int64_t P, const double* tlon,
+                                   const double* tlat, int64_t Tn, double max_dist, int32_t* idx_out, double* dist_out,
+                                   int32_t* tie_list, int64_t* n_ties) {
+    ARG_CHECK(tie_list && n_ties);
+    return nn_query_impl(h, plon, plat, P, tlon, tlat, Tn, max_dist, idx_out, dist_out, tie_list, n_ties);
 }
 
 template <typename T>
@@ -725,23 +802,65 @@ extern "C" int oisat_rbf_interp(oisat_ctx* h, int dtype, const double* plon, con
     return OISAT_OK;
 }
 
+static int linear_impl(oisat_ctx* h, int dtype, const double* tlon, const double* tlat, int64_t Tn, const int32_t* nn_idx,
+                       const int32_t* vertex_to_simplex, const int32_t* simplices, const int32_t* neighbors, const double* transform,
+                       int64_t nsimplex, const void* values, int64_t P, int nfields, void* out, const double* bounds_host,
+                       const int32_t* forced, int32_t* amb_list, int64_t* n_amb) {
+    ARG_CHECK(h && tlon && tlat && nn_idx && vertex_to_simplex && simplices && neighbors && transform);
+    ARG_CHECK(nfields == 0 || (values && out));
+    TriBounds bb = {-1e300, 1e300, -1e300, 1e300};                    // no bounds given: never "fully outside"
+    if (bounds_host) bb = TriBounds{bounds_host[0], bounds_host[1], bounds_host[2], bounds_host[3]};
+    ARG_CHECK(Tn > 0 && Tn < (int64_t)INT32_MAX && nsimplex > 0 && nsimplex < (int64_t)INT32_MAX && P > 0 && nfields >= 0);
+    ARG_CHECK(dtype == OISAT_F32 || dtype == OISAT_F64);
+    unsigned* count = nullptr;
+    unsigned* count_host = nullptr;
+    if (amb_list) {
+        count = (unsigned*)oisat_ws(h, 1, 64);
+        count_host = (unsigned*)oisat_pinned(h, 64);
+        if (!count || !count_host) return OISAT_ENOMEM;
+        HIP_TRY(hipMemsetAsync(count, 0, 64, h->stream));
+    }
+    const int grid = stream_grid(Tn, 256);
+    if (dtype == OISAT_F32) {
+        OISAT_LAUNCH(h, "linear_interp", (linear_interp_kernel<float>), dim3(grid), dim3(256), 0, tlon, tlat, Tn, nn_idx,
+                     vertex_to_simplex, simplices, neighbors, transform, (int32_t)nsimplex, (const float*)values, P, nfields, (float*)out, bb,
+                     forced, amb_list, count);
+    } else {
+        OISAT_LAUNCH(h, "linear_interp", (linear_interp_kernel<double>), dim3(grid), dim3(256), 0, tlon, tlat, Tn, nn_idx,
+                     vertex_to_simplex, simplices, neighbors, transform, (int32_t)nsimplex, (const double*)values, P, nfields,
+                     (double*)out, bb, forced, amb_list, count);
+    }
+    if (amb_list) {
+        HIP_TRY(hipMemcpyAsync(count_host, count, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        *n_amb = (int64_t)count_host[0];
+    }
+    return OISAT_OK;
+}
+
 extern "C" int oisat_linear_interp(oisat_ctx* h, int dtype, const double* tlon, const double* tlat, int64_t Tn, const int32_t* nn_idx,
                                    const int32_t* vertex_to_simplex, const int32_t* simplices, const int32_t* neighbors,
                                    const double* transform, int64_t nsimplex, const void* values, int64_t P, int nfields, void* out,
                                    const double* bounds_host) {
-    ARG_CHECK(h && tlon && tlat && nn_idx && vertex_to_simplex && simplices && neighbors && transform && values && out);
-    TriBounds bb = {-1e300, 1e300, -1e300, 1e300};                    // no bounds given: never "fully outside"
-    if (bounds_host) bb = TriBounds{bounds_host[0], bounds_host[1], bounds_host[2], bounds_host[3]};
-    ARG_CHECK(Tn > 0 && nsimplex > 0 && nsimplex < (int64_t)INT32_MAX && P > 0 && nfields > 0);
-    ARG_CHECK(dtype == OISAT_F32 || dtype == OISAT_F64);
-    const int grid = stream_grid(Tn, 256);
-    if (dtype == OISAT_F32) {
-        OISAT_LAUNCH(h, "linear_interp", (linear_interp_kernel<float>), dim3(grid), dim3(256), 0, tlon, tlat, Tn, nn_idx,
-                     vertex_to_simplex, simplices, neighbors, transform, (int32_t)nsimplex, (const float*)values, P, nfields, (float*)out, bb);
-    } else {
-        OISAT_LAUNCH(h, "linear_interp", (linear_interp_kernel<double>), dim3(grid), dim3(256), 0, tlon, tlat, Tn, nn_idx,
-                     vertex_to_simplex, simplices, neighbors, transform, (int32_t)nsimplex, (const double*)values, P, nfields,
-                     (double*)out, bb);
-    }
-    return OISAT_OK;
+    ARG_CHECK(nfields > 0);
+    return linear_impl(h, dtype, tlon, tlat, Tn, nn_idx, vertex_to_simplex, simplices, neighbors, transform, nsimplex, values, P, nfields,
+                       out, bounds_host, nullptr, nullptr, nullptr);
+}
+
+extern "C" int oisat_linear_locate(oisat_ctx* h, const double* tlon, const double* tlat, int64_t Tn, const int32_t* nn_idx,
+                                   const int32_t* vertex_to_simplex, const int32_t* simplices, const int32_t* neighbors,
+                                   const double* transform, int64_t nsimplex, int64_t P, const double* bounds_host, int32_t* amb_list,
+                                   int64_t* n_amb) {
+    ARG_CHECK(amb_list && n_amb);
+    return linear_impl(h, OISAT_F64, tlon, tlat, Tn, nn_idx, vertex_to_simplex, simplices, neighbors, transform, nsimplex, nullptr, P, 0,
+                       nullptr, bounds_host, nullptr, amb_list, n_amb);
+}
+
+extern "C" int oisat_linear_interp_forced(oisat_ctx* h, int dtype, const double* tlon, const double* tlat, int64_t Tn,
+                                          const int32_t* nn_idx, const int32_t* vertex_to_simplex, const int32_t* simplices,
+                                          const int32_t* neighbors, const double* transform, int64_t nsimplex, const void* values,
+                                          int64_t P, int nfields, void* out, const double* bounds_host, const int32_t* forced) {
+    ARG_CHECK(nfields > 0 && forced);
+    return linear_impl(h, dtype, tlon, tlat, Tn, nn_idx, vertex_to_simplex, simplices, neighbors, transform, nsimplex, values, P, nfields,
+                       out, bounds_host, forced, nullptr, nullptr);
 }

@@ -62,9 +62,15 @@ SIGNATURES = {
     "oisat_pwv_sum": (C.c_int, [_c_ctx, C.c_int, _ptr, C.c_int, _ptr, _i64, _ptr]),
     "oisat_boxfilter_symm": (C.c_int, [_c_ctx, C.c_int, _ptr, _i64, _i64, C.c_int, C.c_int, C.c_int, _ptr]),
     "oisat_nn_query": (C.c_int, [_c_ctx, _ptr, _ptr, _i64, _ptr, _ptr, _i64, C.c_double, _ptr, _ptr]),
+    "oisat_nn_query_ties": (C.c_int, [_c_ctx, _ptr, _ptr, _i64, _ptr, _ptr, _i64, C.c_double, _ptr, _ptr, _ptr,
+                                      C.POINTER(C.c_int64)]),
     "oisat_gather_mask": (C.c_int, [_c_ctx, C.c_int, _ptr, _i64, C.c_int, _ptr, _i64, _ptr]),
     "oisat_linear_interp": (C.c_int, [_c_ctx, C.c_int, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _i64,
                                       C.c_int, _ptr, C.POINTER(C.c_double)]),
+    "oisat_linear_locate": (C.c_int, [_c_ctx, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, C.POINTER(C.c_double),
+                                      _ptr, C.POINTER(C.c_int64)]),
+    "oisat_linear_interp_forced": (C.c_int, [_c_ctx, C.c_int, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _ptr, _i64,
+                                             C.c_int, _ptr, C.POINTER(C.c_double), _ptr]),
     "oisat_rbf_interp": (C.c_int, [_c_ctx, C.c_int, _ptr, _ptr, _i64, _ptr, _ptr, _i64, _ptr, C.c_double, C.c_int, _ptr, C.c_int,
                                    _ptr, C.POINTER(C.c_int64)]),
     "oisat_boxfilter_pick": (C.c_int, [_c_ctx, C.c_int, _ptr, _i64, _i64, C.c_int, C.c_int, C.c_int, C.c_int,

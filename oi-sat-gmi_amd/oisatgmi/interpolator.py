@@ -55,13 +55,23 @@ def _boxfilter2(size_kernel_x, size_kernel_y) -> np.ndarray:
 class NNIndex:
     """Device-resident stand-in for the ``cKDTree`` / ``Delaunay`` objects the reference threads
     through ``_interpolosis``: the source points live in HBM and ``query`` runs the bounded-radius
-    exact neighbour search of csrc/regrid.hip."""
+    exact neighbour search of csrc/regrid.hip.
+
+    Exact ties.  Where a target is equidistant from several points, ``cKDTree.query`` returns whichever of
+    them its traversal meets first -- a property of scipy's tree, not of the geometry -- and the reference's
+    own settings produce such targets (``grid_size = 1.0`` against a 1.25 / 2.5 degree model longitude spacing,
+    reader.py:1209,:1271).  The device search reports them (``oisat_nn_query_ties``) and exactly those targets
+    are re-queried against the tree the reference builds over the same point array (interpolator.py:78-88,
+    :145-150), once per grid pair; the triangulation of type 1 is taken from qhull in the same way."""
 
     def __init__(self, lon, lat):
         self.ctx = _hip.context()
         lon = np.ascontiguousarray(np.ravel(lon), dtype=np.float64)
         lat = np.ascontiguousarray(np.ravel(lat), dtype=np.float64)
         self.P = lon.size
+        self.lon, self.lat = lon, lat
+        self._tree = None
+        self.ties_resolved = 0
         self.buf = self.ctx.alloc(2 * self.P * 8)
         self.ctx.upload_into(self.buf.at(0), lon)
         self.ctx.upload_into(self.buf.at(self.P * 8), lat)
@@ -78,7 +88,14 @@ class NNIndex:
         pts = np.asarray(obj)
         return cls(pts[:, 0], pts[:, 1])
 
-    def query_device(self, tlon, tlat, max_dist, want_dist=False):
+    def tree(self):
+        """``cKDTree(points)`` over the very array the reference builds it from (interpolator.py:78-82)."""
+        if self._tree is None:
+            from scipy.spatial import cKDTree
+            self._tree = cKDTree(np.column_stack((self.lon, self.lat)))
+        return self._tree
+
+    def query_device(self, tlon, tlat, max_dist, want_dist=False, resolve_ties=True):
         """-> (DeviceBuffer int32[T] of point indices (-1 = beyond max_dist), dist buffer or None)"""
         ctx = self.ctx
         tlon = np.ascontiguousarray(np.ravel(tlon), dtype=np.float64)
@@ -89,10 +106,28 @@ class NNIndex:
         ctx.upload_into(tb.at(T * 8), tlat)
         idx = ctx.alloc(T * 4)
         dist = ctx.alloc(T * 8) if want_dist else None
-        ctx.check(ctx.lib.oisat_nn_query(ctx.h, self.buf.at(0), self.buf.at(self.P * 8), self.P, tb.at(0), tb.at(T * 8),
-                                         T, float(max_dist), idx.ptr, dist.ptr if dist else None))
+        if not resolve_ties:
+            ctx.check(ctx.lib.oisat_nn_query(ctx.h, self.buf.at(0), self.buf.at(self.P * 8), self.P, tb.at(0), tb.at(T * 8),
+                                             T, float(max_dist), idx.ptr, dist.ptr if dist else None))
+            ctx.sync()
+            tb.free()
+            return idx, dist
+        ties = ctx.alloc(T * 4)
+        n = _hip.C.c_int64(0)
+        ctx.check(ctx.lib.oisat_nn_query_ties(ctx.h, self.buf.at(0), self.buf.at(self.P * 8), self.P, tb.at(0), tb.at(T * 8),
+                                              T, float(max_dist), idx.ptr, dist.ptr if dist else None, ties.ptr,
+                                              _hip.C.byref(n)))
         ctx.sync()
         tb.free()
+        if n.value:
+            which = np.sort(ctx.download(ties.ptr, (int(n.value),), _I32))
+            _, pick = self.tree().query(np.column_stack((tlon[which], tlat[which])))
+            host = ctx.download(idx.ptr, (T,), _I32)
+            host[which] = pick.astype(np.int32)
+            ctx.upload_into(idx.at(0), host)
+            ctx.sync()
+            self.ties_resolved += int(n.value)
+        ties.free()
         return idx, dist
 
     def query(self, targets, max_dist=np.inf):
@@ -117,6 +152,8 @@ class TriIndex:
         self.transform = ctx.upload(tri.transform, dtype=np.float64)
         self.v2s = ctx.upload(tri.vertex_to_simplex, dtype=np.int32)
         self.P = int(tri.points.shape[0])
+        self.ambiguous = 0
+        self.has_degenerate = bool(np.isnan(tri.transform[:, 0, 0]).any())
         self.bounds = (_hip.C.c_double * 4)(float(tri.min_bound[0]), float(tri.max_bound[0]), float(tri.min_bound[1]),
                                              float(tri.max_bound[1]))
 
@@ -130,9 +167,47 @@ class TriIndex:
         except Exception:
             return None
 
-    def interpolate(self, dt, values_buf, nfields, tgt_buf, T, nn_idx_buf):
+    def locate(self, tgt_buf, T, nn_idx_buf, tlon, tlat):
+        """Simplices for the targets whose location is not unique (on a shared facet / vertex, or found by the brute-force
+        scan): scipy evaluates targets one after the other, each walk starting where the previous one ended, so the simplex
+        such a target gets -- and, next to a NaN vertex, whether the output is NaN -- is a property of that sequential
+        search.  Exactly those targets are therefore located by ``Delaunay.find_simplex`` over the whole target list (same
+        walk, same order, same eps as LinearNDInterpolator, interpolator.py:13-15); every other target keeps the device
+        walk (a proper triangulation is a partition: strictly inside one simplex means inside no other).  -> DeviceBuffer int32[T] (-2 = walk on the device) or None when no target is ambiguous (any jittered swath)."""
+        ctx = self.ctx
+        if self.has_degenerate:
+            # qhull closed the hull with zero-area simplices (NaN transforms): the triangulation is then not a partition
+            # -- large flat simplices overlap their neighbours -- and "the" simplex of a target is whatever the sequential
+            # search returns, for any target.  Take all of them from it.
+            found = self.tri.find_simplex(np.column_stack((np.ravel(tlon), np.ravel(tlat))).astype(np.float64))
+            self.ambiguous = int(T)
+            return ctx.upload(found.astype(np.int32))
+        amb = ctx.alloc(T * 4)
+        n = _hip.C.c_int64(0)
+        ctx.check(ctx.lib.oisat_linear_locate(ctx.h, tgt_buf.at(0), tgt_buf.at(T * 8), T, nn_idx_buf.ptr, self.v2s.ptr,
+                                              self.simplices.ptr, self.neighbors.ptr, self.transform.ptr, self.ns, self.P,
+                                              self.bounds, amb.ptr, _hip.C.byref(n)))
+        ctx.sync()
+        self.ambiguous = int(n.value)
+        if not n.value:
+            amb.free()
+            return None
+        which = np.sort(ctx.download(amb.ptr, (int(n.value),), _I32))
+        amb.free()
+        found = self.tri.find_simplex(np.column_stack((np.ravel(tlon), np.ravel(tlat))).astype(np.float64))
+        forced = np.full(T, -2, dtype=np.int32)
+        forced[which] = found[which]
+        return ctx.upload(forced)
+
+    def interpolate(self, dt, values_buf, nfields, tgt_buf, T, nn_idx_buf, forced=None):
         ctx = self.ctx
         out = ctx.alloc(nfields * T * dt.itemsize)
+        if forced is not None:
+            ctx.check(ctx.lib.oisat_linear_interp_forced(ctx.h, _hip.dtype_code(dt), tgt_buf.at(0), tgt_buf.at(T * 8), T,
+                                                         nn_idx_buf.ptr, self.v2s.ptr, self.simplices.ptr, self.neighbors.ptr,
+                                                         self.transform.ptr, self.ns, values_buf.ptr, self.P, nfields, out.ptr,
+                                                         self.bounds, forced.ptr))
+            return out
         ctx.check(ctx.lib.oisat_linear_interp(ctx.h, _hip.dtype_code(dt), tgt_buf.at(0), tgt_buf.at(T * 8), T, nn_idx_buf.ptr,
                                               self.v2s.ptr, self.simplices.ptr, self.neighbors.ptr, self.transform.ptr, self.ns,
                                               values_buf.ptr, self.P, nfields, out.ptr, self.bounds))
@@ -175,7 +250,7 @@ def _interpolosis(interpol_func, Z: np.ndarray, X: np.ndarray, Y: np.ndarray, in
         ctx.upload_into(tb.at(0), np.ravel(X), dtype=np.float64)
         ctx.upload_into(tb.at(T * 8), np.ravel(Y), dtype=np.float64)
         cell = 2.0 * float(threshold)
-        idx, _ = nn.query_device(X, Y, cell)
+        idx, _ = nn.query_device(X, Y, cell, resolve_ties=False)     # only decides which targets are skipped
         out = _rbf(nn, dt, Zb, 1, tb, T, idx, cell)
         ZZ = ctx.download(out.ptr, np.shape(X), dt)
         ZZ[np.asarray(dists) > threshold * 2.0] = np.nan
@@ -192,8 +267,8 @@ def _interpolosis(interpol_func, Z: np.ndarray, X: np.ndarray, Y: np.ndarray, in
         ctx.upload_into(tb.at(T * 8), np.ravel(Y), dtype=np.float64)
         # walk start: nearest pixel of every target (unbounded radius here; the mask comes from `dists`)
         span = float(np.hypot(np.ptp(pts[:, 0]) + np.ptp(np.ravel(X)), np.ptp(pts[:, 1]) + np.ptp(np.ravel(Y)))) + 1.0
-        idx, _ = nn.query_device(X, Y, span)
-        out = ti.interpolate(dt, Zb, 1, tb, T, idx)
+        idx, _ = nn.query_device(X, Y, span, resolve_ties=False)     # walk start only
+        out = ti.interpolate(dt, Zb, 1, tb, T, idx, ti.locate(tb, T, idx, X, Y))
         ZZ = ctx.download(out.ptr, np.shape(X), dt)
         ZZ[np.asarray(dists) > threshold * 2.0] = np.nan
         return ZZ
@@ -220,6 +295,7 @@ class _UpscalePlan:
         self.ctm_longitude = ctm_longitude
         self.ctm_latitude = ctm_latitude
         self.needed = bool((dlon >= grid_size) or (dlat >= grid_size))        # interpolator.py:64
+        self.ties_resolved = 0
         self.Ny, self.Nx = np.shape(X)
         if not self.needed:
             return
@@ -231,6 +307,7 @@ class _UpscalePlan:
         self.T = int(np.size(ctm_latitude))
         nn = NNIndex(X, Y)                                      # every fine node is a candidate (:78-82)
         self.idx, _ = nn.query_device(ctm_longitude, ctm_latitude, 2.0 * float(threshold))     # :83-91
+        self.ties_resolved = nn.ties_resolved               # model centres equidistant from several fine nodes
         self.ctx = nn.ctx
 
     def run(self, fine_buf, nfields, dt, variance):
@@ -321,13 +398,19 @@ class _GranuleRegridder:
         self.qflag_host = np.squeeze(sat_data.quality_flag)
         self.nn = nn = NNIndex(sat_data.longitude_center, sat_data.latitude_center)
         self.cell = 2.0 * float(grid_size)
-        self.idx_fine, _ = nn.query_device(self.lons_grid, self.lats_grid, self.cell)   # :145-150,:16-33
+        # types 2 / 4 gather through this index (ties as the reference's tree breaks them); types 1 / 3 only use it as the
+        # walk start / the `dists` mask, where a tie changes nothing
+        self.idx_fine, _ = nn.query_device(self.lons_grid, self.lats_grid, self.cell,   # :145-150,:16-33
+                                           resolve_ties=self.kind in (2, 4))
         self.plan = _upscale_plan(self.lons_grid, self.lats_grid, ctm_models_coordinate, grid_size, threshold_ctm)
         self._flag_bufs = {}
         if self.kind in (1, 3):
             self.tgt = ctx.alloc(2 * self.Tfine * 8)
             ctx.upload_into(self.tgt.at(0), np.ravel(self.lons_grid), dtype=np.float64)
             ctx.upload_into(self.tgt.at(self.Tfine * 8), np.ravel(self.lats_grid), dtype=np.float64)
+        self.forced = None
+        if self.kind == 1:              # once per granule; the reference repeats the search for every field
+            self.forced = self.tri.locate(self.tgt, self.Tfine, self.idx_fine, self.lons_grid, self.lats_grid)
 
     def _flag(self, dt):
         b = self._flag_bufs.get(dt)
@@ -357,7 +440,7 @@ class _GranuleRegridder:
             ctx.check(ctx.lib.oisat_flag_mask(ctx.h, code, raw.at(f * self.P * item), flag.ptr, self.P, self.flag_thresh,
                                               0, masked.at(f * self.P * item)))
         if self.kind == 1:               # targets beyond 2*grid_size of any pixel carry idx -1 -> NaN, like the dists mask
-            fine = self.tri.interpolate(dt, masked, nf, self.tgt, self.Tfine, self.idx_fine)
+            fine = self.tri.interpolate(dt, masked, nf, self.tgt, self.Tfine, self.idx_fine, self.forced)
         elif self.kind == 3:
             fine = _rbf(self.nn, dt, masked, nf, self.tgt, self.Tfine, self.idx_fine, self.cell)
         else:

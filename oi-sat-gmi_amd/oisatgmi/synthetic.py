@@ -279,6 +279,38 @@ def swath_level_granule(seed: int, kind: str = "amf", nz: int = 3, nscan: int = 
                          1800.0 + 40.0 * smooth + rng.normal(size=shape), pw, kind)
 
 
+def lattice_l3_granule(seed: int, sensor: str = "MOPITT", nz: int = 3, lat0: float = -19.5, lat1: float = 19.5,
+                       lon0: float = -29.5, lon1: float = 29.5, step: float = 1.0):
+    """A gridded (level-3) ``satellite_opt`` record as reader.py:1150-1203 hands MOPITT MOP03 files to
+    ``interpolator``: cell centres on an exact ``step``-degree lattice read as float32 and laid out lon-major
+    (``meshgrid`` + transpose, reader.py:1157-1160), quality flag all ones (``flag_thresh=0.0`` at the call site,
+    reader.py:1209-1211), NaN holes in the retrieved column.  With ``grid_size = step`` every fine-grid node the
+    reference builds (interpolator.py:141-143) sits exactly between lattice centres, and every model centre at x.5
+    exactly between fine nodes: the exact nearest-neighbour ties of SURVEY section 8(a) row a7."""
+    from .config import satellite_opt
+    rng = np.random.default_rng(seed)
+    lon1d = np.arange(lon0, lon1 + 1e-9, step).astype(np.float32)
+    lat1d = np.arange(lat0, lat1 + 1e-9, step).astype(np.float32)
+    lon, lat = np.meshgrid(lon1d, lat1d)
+    lon, lat = np.transpose(lon), np.transpose(lat)
+    shape = lat.shape
+    vcd = 2.0 + np.sin(np.deg2rad(6 * lon)) * np.cos(np.deg2rad(5 * lat)) + 0.05 * rng.normal(size=shape)
+    vcd[rng.uniform(size=shape) < 0.03] = np.nan
+    unc = rng.uniform(0.1, 0.6, size=shape).astype(np.float32)
+    smooth = 1.0 + 0.3 * np.sin(np.deg2rad(7 * lon + 3 * lat))
+    pmid = np.linspace(950.0, 120.0, nz)[:, None, None] * np.ones((nz,) + shape)
+    nak = nz + 1 if sensor == "MOPITT" else nz
+    ak = np.linspace(0.2, 1.2, nak)[:, None, None] * smooth[None] + 0.01 * rng.normal(size=(nak,) + shape)
+    apro = np.linspace(90.0, 40.0, nz)[:, None, None] * smooth[None]
+    pw = np.empty((1))
+    if sensor == "GOSAT":
+        pw = np.full((nz,) + shape, 1.0 / nz) * (1.0 + 0.05 * rng.normal(size=(nz,) + shape))
+    when = _dt.datetime(2019, 6, 15, 10, 30)
+    return satellite_opt(vcd, when, [], np.empty((1)), lat, lon, [], [], unc, np.ones_like(vcd), pmid, ak, [], [], [], [],
+                         18.0 + 0.2 * smooth, apro, 1000.0 - 20.0 * smooth, 80.0 * smooth,
+                         1800.0 + 40.0 * smooth + rng.normal(size=shape), pw, sensor)
+
+
 def regional_ctm_grid(lat0: float, lat1: float, lon0: float, lon1: float, dlat: float, dlon: float):
     """Model-grid coordinate dict in the layout the readers hand to ``interpolator``
     (``{'Latitude': 2-D, 'Longitude': 2-D}``, interpolator.py:117-118)."""

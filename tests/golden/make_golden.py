@@ -275,6 +275,64 @@ def gen_interpolator_levels():
     save("interpolator_levels.npz", **out)
 
 
+def _fine_grid(ctm, gs):
+    """the fine grid exactly as interpolator() builds it (interpolator.py:136-143)"""
+    lat, lon = ctm["Latitude"], ctm["Longitude"]
+    lon_grid = np.arange(np.min(lon), np.max(lon) + gs, gs)
+    lat_grid = np.arange(np.min(lat), np.max(lat) + gs, gs)
+    return np.meshgrid(lon_grid, lat_grid)
+
+
+TIE_GRIDS = {   # tag -> (lat0, lat1, lon0, lon1, dlat, dlon, grid_size): the reference's MOPITT / GOSAT settings
+    "gs100_1x125": (-20.0, 20.0, -30.0, 30.0, 1.0, 1.25, 1.0),        # grid_size 1.0 (reader.py:1209,:1271), GMI 1 x 1.25
+    "gs100_2x25": (-20.0, 20.0, -30.0, 30.0, 2.0, 2.5, 1.0),          # grid_size 1.0, GMI 2 x 2.5
+    "gs025_05x0625": (-10.0, 10.0, -15.0, 15.0, 0.5, 0.625, 0.25),    # 0.25 deg, MERRA2-GMI 0.5 x 0.625
+    "global_1x125": (-90.0, 90.0, -180.0, 178.75, 1.0, 1.25, 1.0),    # the whole 181 x 288 model grid
+}
+
+
+def gen_upscaler_ties():
+    """_upscaler / interpolator() where model cell centres lie EXACTLY midway between fine-grid nodes, so the
+    reference's cKDTree(points).query(xi) (interpolator.py:78-91) has to pick among equidistant nodes: the model
+    longitude spacing 1.25 / 2.5 deg against grid_size 1.0 (MOPITT, GOSAT), 0.625 against 0.25.  'index' fields carry
+    the fine node's flat index (identifies the pick outright when the box kernel is 1x1), 'rand' fields distinct
+    random values with NaN holes (identify it through the box average)."""
+    out = {}
+    rng = np.random.default_rng(3113)
+    for tag, (la0, la1, lo0, lo1, dlat, dlon, gs) in TIE_GRIDS.items():
+        ctm = syn.regional_ctm_grid(la0, la1, lo0, lo1, dlat, dlon)
+        X, Y = _fine_grid(ctm, gs)
+        thr = np.sqrt(dlat ** 2 + dlon ** 2)
+        Zi = np.arange(X.size, dtype=np.float64).reshape(X.shape)
+        Zr = rng.uniform(1.0, 2.0, size=X.shape)
+        Zr[rng.uniform(size=X.shape) < 0.02] = np.nan
+        out[f"{tag}_spec"] = np.array([la0, la1, lo0, lo1, dlat, dlon, gs])
+        out[f"{tag}_X"], out[f"{tag}_Y"], out[f"{tag}_Zrand"] = X, Y, Zr
+        out[f"{tag}_clat"], out[f"{tag}_clon"] = ctm["Latitude"], ctm["Longitude"]
+        for nm, Z in (("index", Zi), ("rand", Zr)):
+            for err in (False, True):
+                _, _, oz, need = REF_interp._upscaler(X, Y, Z.copy(), ctm, gs, thr, error=err)
+                assert need is False
+                out[f"{tag}_{nm}_{'var' if err else 'mean'}"] = oz
+    # interpolator() on level-3 lattice records (MOPITT MOP03 style: reader.py:1150-1211, grid_size 1.0, type 1,
+    # flag_thresh 0.0), plus type 4 where the swath -> fine-grid search itself meets four-way ties
+    for sensor, seed, grid in (("MOPITT", 6201, "gs100_1x125"), ("MOPITT", 6201, "gs100_2x25"), ("GOSAT", 6202, "gs100_2x25")):
+        la0, la1, lo0, lo1, dlat, dlon, gs = TIE_GRIDS[grid]
+        ctm = syn.regional_ctm_grid(la0, la1, lo0, lo1, dlat, dlon)
+        g = syn.lattice_l3_granule(seed, sensor=sensor)
+        for it in (1, 4):
+            r = quiet(REF_interp.interpolator, it, gs, to_ref(g), ctm, 0.0)
+            assert r is not None
+            names = []
+            for f in dataclasses.fields(r):
+                v = getattr(r, f.name)
+                if isinstance(v, np.ndarray):
+                    out[f"l3_{sensor}_{grid}_t{it}_{f.name}"] = v
+                    names.append(f.name)
+            out[f"l3_{sensor}_{grid}_t{it}_arrays"] = np.array(names)
+    save("upscaler_ties.npz", **out)
+
+
 def gen_linear_degenerate():
     """_interpolosis type 1 on a triangulation that holds DEGENERATE simplices (NaN barycentric transforms): an exactly
     regular pixel lattice whose latitudes carry 1e-13 deg of noise, so qhull closes the hull with zero-area slivers.
@@ -417,6 +475,9 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["pwv"]:
         gen_pwv()
         raise SystemExit(0)
+    if sys.argv[1:] == ["ties"]:
+        gen_upscaler_ties()
+        raise SystemExit(0)
     gen_records()
     gen_oi("72x144", 72, 144, 1000, 1001, full=True)
     gen_oi("360x720", 360, 720, 10000, 2001, full=False)
@@ -429,6 +490,7 @@ if __name__ == "__main__":
     gen_interpolator_rbf()
     gen_interpolator_levels()
     gen_linear_degenerate()
+    gen_upscaler_ties()
     gen_amf_recal()
     gen_ak_conv()
     gen_pwv()

@@ -380,13 +380,9 @@ def test_linear_interpolation_survives_degenerate_simplices(ctx, golden):
     got = _interpolosis(tri, g["Z"], g["X"], g["Y"], 1, g["dists"], 0.25)
     assert np.array_equal(np.isnan(got), np.isnan(g["out"]))
     # A target within eps_broad of a zero-area simplex lies "inside" more than one simplex; scipy returns whichever its
-    # SEQUENTIAL walk (each target starts from the previous target's simplex) meets first, the device walk starts at the
-    # target's nearest pixel.  Everywhere else the containing simplex is unique and the values agree to rounding; the
-    # ambiguous targets (1 of 7049 here) still agree to the interpolation error of the sliver's neighbours.
-    with np.errstate(invalid="ignore"):
-        off = ~(np.abs(got - g["out"]) <= RT64 * np.abs(g["out"])) & ~np.isnan(got)
-    assert off.sum() <= 3, int(off.sum())
-    assert np.abs(got[off] - g["out"][off]).max(initial=0.0) <= 1e-3 * np.nanmax(np.abs(g["out"]))
+    # SEQUENTIAL walk (each target starts from the previous target's simplex) meets first.  Round 3: the device reports
+    # such targets (oisat_linear_locate) and they are located by scipy's own sequential search, so every target agrees.
+    np.testing.assert_allclose(got, g["out"], rtol=RT64, atol=0, equal_nan=True)
 
 
 def test_batched_factorization_is_bit_identical(ctx):

@@ -119,6 +119,80 @@ def test_interpolator(golden):
     assert bool(g["miss_is_none"])
 
 
+TIE_GRIDS = ("gs100_1x125", "gs100_2x25", "gs025_05x0625", "global_1x125")
+L3_CASES = (("MOPITT", 6201, "gs100_1x125"), ("MOPITT", 6201, "gs100_2x25"), ("GOSAT", 6202, "gs100_2x25"))
+
+
+def tie_case(g, tag):
+    """(X, Y, ctm dict, grid_size, threshold, {name: Z}) of one exact-tie grid pair of upscaler_ties.npz; the fine grid is
+    rebuilt the way interpolator() builds it (interpolator.py:136-143) and checked against the stored one."""
+    la0, la1, lo0, lo1, dlat, dlon, gs = (float(v) for v in g[f"{tag}_spec"])
+    ctm = {"Latitude": g[f"{tag}_clat"], "Longitude": g[f"{tag}_clon"]}
+    X, Y = np.meshgrid(np.arange(ctm["Longitude"].min(), ctm["Longitude"].max() + gs, gs),
+                       np.arange(ctm["Latitude"].min(), ctm["Latitude"].max() + gs, gs))
+    np.testing.assert_array_equal(X, g[f"{tag}_X"])
+    np.testing.assert_array_equal(Y, g[f"{tag}_Y"])
+    fields = {"index": np.arange(X.size, dtype=np.float64).reshape(X.shape), "rand": g[f"{tag}_Zrand"]}
+    return X, Y, ctm, gs, float(np.sqrt(dlat ** 2 + dlon ** 2)), fields
+
+
+def count_exact_ties(X, Y, ctm):
+    """model centres with two or more equidistant nearest fine nodes (regular grids: per-axis argmin multiplicity)"""
+    def axis_ties(nodes, centres):
+        d = np.abs(nodes[None, :] - centres[:, None])
+        return (d == d.min(axis=1, keepdims=True)).sum(axis=1) > 1
+    tx = axis_ties(X[0], ctm["Longitude"][0])
+    ty = axis_ties(Y[:, 0], ctm["Latitude"][:, 0])
+    return int((tx[None, :] | ty[:, None]).sum())
+
+
+def check_tie_fields(g, tag, run):
+    """run(Z, error) -> model-grid field; compared with the reference's _upscaler outputs: NaN pattern bit-equal, 1e-12"""
+    for nm in ("index", "rand"):
+        for err in (False, True):
+            want = g[f"{tag}_{nm}_{'var' if err else 'mean'}"]
+            got = run(nm, err)
+            assert got.shape == want.shape
+            assert np.array_equal(np.isnan(got), np.isnan(want)), (tag, nm, err)
+            np.testing.assert_allclose(got, want, rtol=1e-12, atol=0, equal_nan=True, err_msg=f"{tag} {nm} error={err}")
+
+
+@pytest.mark.parametrize("tag", TIE_GRIDS)
+def test_upscaler_exact_ties(golden, tag):
+    """Model centres exactly midway between fine nodes (grid_size 1.0 vs 1.25 / 2.5 deg, reader.py:1209,:1271; 0.25 vs
+    0.625): the pick among equidistant nodes is cKDTree's, and the oracle builds the same tree (interpolator.py:78-91)."""
+    g = golden("upscaler_ties.npz")
+    X, Y, ctm, gs, thr, fields = tie_case(g, tag)
+    assert count_exact_ties(X, Y, ctm) > 0.2 * ctm["Latitude"].size          # the fixture really is about ties
+    check_tie_fields(g, tag, lambda nm, err: orc.upscaler(X, Y, fields[nm].copy(), ctm, gs, thr, error=err)[2])
+
+
+def check_l3_record(g, sensor, grid, it, r, rtol):
+    assert isinstance(r, cfg.satellite_opt)
+    for name in g[f"l3_{sensor}_{grid}_t{it}_arrays"]:
+        want = g[f"l3_{sensor}_{grid}_t{it}_{name}"]
+        got = np.asarray(getattr(r, str(name)))
+        if want.shape == (1,):
+            assert got.shape == (1,)
+            continue
+        assert got.shape == want.shape, (sensor, grid, it, name)
+        assert np.array_equal(np.isnan(got), np.isnan(want)), (sensor, grid, it, name)
+        np.testing.assert_allclose(got, want, rtol=rtol, atol=0, equal_nan=True, err_msg=f"{sensor} {grid} type {it} {name}")
+
+
+@pytest.mark.parametrize("sensor,seed,grid", L3_CASES)
+def test_interpolator_lattice_l3_ties(golden, sensor, seed, grid):
+    """interpolator() on a level-3 lattice record (MOPITT MOP03 style, reader.py:1150-1211: grid_size 1.0, flag 0.0):
+    every fine node is equidistant from four lattice centres (type 4 gathers through that tie) and every other model
+    centre from two fine nodes."""
+    g = golden("upscaler_ties.npz")
+    ctm = {"Latitude": g[f"{grid}_clat"], "Longitude": g[f"{grid}_clon"]}
+    s = syn.lattice_l3_granule(seed, sensor=sensor)
+    for it in (1, 4):
+        r = orc.interpolator(it, float(g[f"{grid}_spec"][6]), s, ctm, 0.0, record_type=cfg.satellite_opt)
+        check_l3_record(g, sensor, grid, it, r, 1e-12)
+
+
 LEVEL_KINDS = {"amf": 6101, "MOPITT": 6102, "GOSAT": 6103}
 
 
