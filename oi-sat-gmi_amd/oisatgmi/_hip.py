@@ -187,11 +187,12 @@ def compute_dtype(*arrays) -> np.dtype:
 class DeviceBuffer:
     """A block of HBM owned through the C-ABI (``oisat_dmalloc``/``oisat_dfree``)."""
 
-    __slots__ = ("ctx", "ptr", "nbytes")
+    __slots__ = ("ctx", "ptr", "nbytes", "foreign")
 
     def __init__(self, ctx: "Context", nbytes: int):
         self.ctx = ctx
         self.nbytes = int(nbytes)
+        self.foreign = False
         cached = ctx._take_cached(self.nbytes)
         if cached is not None:
             self.ptr = cached
@@ -200,9 +201,16 @@ class DeviceBuffer:
         ctx.check(ctx.lib.oisat_dmalloc(ctx.h, max(self.nbytes, 16), C.byref(p)))
         self.ptr = p.value
 
+    def shared_with_other_streams(self):
+        """Mark a buffer that streams other than its handle's also touch (a factor the BatchedFactor group streams work on,
+        a slab torch's RCCL stream reads): it is then never parked in the handle's reuse cache -- which orders a reused
+        buffer only behind the OWNING stream -- but released through ``hipFree``, which waits for the whole device."""
+        self.foreign = True
+        return self
+
     def free(self):
         if self.ptr is not None and self.ctx is not None and self.ctx.h is not None:
-            if not self.ctx._give_cached(self.nbytes, self.ptr):
+            if self.foreign or not self.ctx._give_cached(self.nbytes, self.ptr):
                 self.ctx.lib.oisat_dfree(self.ctx.h, self.ptr)
         self.ptr = None
 
@@ -230,8 +238,8 @@ class Context:
         self.device = int(device)
         # Freed buffers of up to 256 MB are parked (2 GB at most) and handed out again for a request of exactly the same
         # size: the drop-in calls (OI, averaging, interpolator) allocate the same handful of sizes on every call, and a
-        # hipMalloc / hipFree pair costs more than the kernels they bracket.  One stream per handle, so a reused buffer
-        # is always ordered behind whatever last touched it.
+        # hipMalloc / hipFree pair costs more than the kernels they bracket.  A parked buffer is ordered behind its OWN
+        # handle's stream only, so buffers that other streams touch opt out (DeviceBuffer.shared_with_other_streams).
         self._cache = {}
         self._cache_bytes = 0
         self._cache_lock = threading.Lock()

@@ -72,7 +72,8 @@ class DenseAnalysis:
         self.glat = c.upload(np.ravel(grid_lat), dtype=np.float64)       # latitude window of apply_increment
         item = self.dt.itemsize
         if out_ptr is None:
-            self.fields = c.alloc(3 * self.n * item)        # xb | xa | inc
+            # xb | xa | inc; read by torch's RCCL stream when the fields are gathered (parallel.FieldGather)
+            self.fields = c.alloc(3 * self.n * item).shared_with_other_streams()
             self.xb_ptr, self.out_ptr = self.fields.at(0), self.fields.at(self.n * item)
         else:
             self.fields = c.alloc(self.n * item)            # xb; xa | inc live in the caller's slab
@@ -88,12 +89,15 @@ class DenseAnalysis:
         self.d = c.alloc(m * 8)
         self.z = c.alloc(m * 8)
         # the factor workspace can be shared by analyses that run one after another on the stream (tiles)
+        # (a batched plan's S and inverted diagonal blocks are worked on by the BatchedFactor group streams)
         self.S = shared_S if shared_S is not None else c.alloc(self.mp_max * self.mp_max * 4)
+        if shared_S is None and batched:
+            self.S.shared_with_other_streams()
         if self.S.nbytes < self.mp_max * self.mp_max * 4:
             raise ValueError("shared_S is too small for max_obs")
         # batched factorization (BatchedFactor): the inverted diagonal blocks live in a buffer of this plan, not in the
         # handle's workspace, because many plans of one handle are factored at the same time
-        self.tinv = c.alloc(self.mp_max * NB * 4) if batched else None
+        self.tinv = c.alloc(self.mp_max * NB * 4).shared_with_other_streams() if batched else None
         self.m = 0
         self._direct_innovation = False
         # every internal workspace of the solve is sized here, so that run() never allocates (include/oisat.h)
@@ -545,6 +549,9 @@ class TiledAnalysis:
         if not self.batched:
             for k, m in enumerate(sizes):
                 self.pool.factors[lane_of[k]].reserve(m)
+        if self.factor is not None:                      # its group streams may still be working on the OLD plans' factors
+            self.factor.close()
+            self.factor = None
         self.plans = [None] * len(self.tiles)
         for k, ti in enumerate(self.live):
             t = self.tiles[ti]
@@ -560,9 +567,6 @@ class TiledAnalysis:
         self._order = [self.live[k] for k in (order if order is not None else range(len(self.live)))]
         self._lane_of = {ti: lane_of[k] for k, ti in enumerate(self.live)}
         self._host = None
-        if self.factor is not None:
-            self.factor.close()
-            self.factor = None
         if self.batched and group and self.live:
             self.factor = BatchedFactor(self.ctx.device, [self.plans[ti] for ti in self.live])
 
@@ -576,7 +580,7 @@ class TiledAnalysis:
             per_lane[self._lane_of[ti]].append(lambda p=self.plans[ti]: fn(p))
         return per_lane
 
-    def enqueue(self, L_km, refine=1, check_pd=False):
+    def enqueue(self, L_km, refine=2, check_pd=False):
         if not self._order:                              # not a single observation in any owned tile: x_a = x_b
             return
         if not self.batched:
@@ -588,7 +592,7 @@ class TiledAnalysis:
             plans[self._lane_of[ti]].append(self.plans[ti])
         self.factor.run(self.pool, plans, refine, check_pd=check_pd)            # lock-step factor | gain solve, increment
 
-    def run(self, L_km, refine=1, check_pd=False):
+    def run(self, L_km, refine=2, check_pd=False):
         """Enqueue every tile on its lane's stream (largest first), wait for all lanes and check their solve status:
         a non-positive pivot or a triangular-solve time-out in ANY tile raises ``OisatError``."""
         self.ctx.sync()                                 # inputs uploaded on the default stream are complete
@@ -673,7 +677,7 @@ class MonthTileBatch:
             self.offsets.append(total)
             total += 2 * (y1 - y0) * (x1 - x0)
         self.slab_elems = total
-        self.slab = self.ctx.alloc(max(total, int(min_slab_elems), 1) * item)
+        self.slab = self.ctx.alloc(max(total, int(min_slab_elems), 1) * item).shared_with_other_streams()   # lanes write, RCCL reads
         self.ctx.check(self.ctx.lib.oisat_memset(self.ctx.h, self.slab.ptr, 0, self.slab.nbytes))
         k0 = 0
         for key, ta in self.months.items():              # units of one month are contiguous in self.units
@@ -686,7 +690,7 @@ class MonthTileBatch:
         self._run_order = [self.units[i][:2] for i in order]
         self.flops = sum(ta.flops for ta in self.months.values())
 
-    def run(self, L_km, refine=1, check_pd=False, wait=True):
+    def run(self, L_km, refine=2, check_pd=False, wait=True):
         self.ctx.sync()
         def per_lane(fn):
             out = [[] for _ in self.pool.lanes]

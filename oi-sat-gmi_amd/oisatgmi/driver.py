@@ -65,6 +65,8 @@ class oisatgmi(object):
     #   unobserved  attribute `oi_unobserved`  | env OISAT_UNOBSERVED     nan (default) | xa        (dense, tiled)
     #   grid        attributes `grid_lat`, `grid_lon` (ny, nx), else the first granule's latitude_center/longitude_center
     #   knee        attribute `oi_reg_index`: force the index into the 99-scaling sweep (all modes)
+    #   error/AK    attribute `oi_want_error`  | env OISAT_OI_ERROR       1 (default) | 0: error_OI / ak_OI left NaN -- the
+    #               posterior error costs n m^2 flop, 1e16 for a global 720x1440 / 1e5-observation analysis (dense, tiled)
     def _oi_setting(self, attr, env, default, cast=str):
         v = getattr(self, attr, None)
         if v is None:
@@ -100,40 +102,67 @@ class oisatgmi(object):
             return
         if mode not in ("dense", "tiled"):
             raise ValueError(f"OISAT_OI_MODE / oi_mode must be diag, dense or tiled, not {mode!r}")
-        from . import dense
-        from . import optimal_interpolation as oi_mod
         L = self._oi_setting("corr_length_km", "OISAT_CORR_LENGTH_KM", 300.0, float)
         unobserved = self._oi_setting("oi_unobserved", "OISAT_UNOBSERVED", "nan").lower()
         if unobserved not in ("nan", "xa"):
             raise ValueError(f"OISAT_UNOBSERVED / oi_unobserved must be nan or xa, not {unobserved!r}")
+        want_error = self._oi_setting("oi_want_error", "OISAT_OI_ERROR", "1").lower() not in ("0", "false", "no", "off")
         lat, lon = self._oi_grid()
+        xa, y = np.asarray(xa), np.asarray(y)
+        if lat.shape != xa.shape[:2] or lon.shape != xa.shape[:2]:
+            raise ValueError(f"oi(): the grid is {lat.shape} but the averaged fields are {xa.shape}; set grid_lat / grid_lon "
+                             f"(ny, nx) to the model grid the fields live on")
         print('Optimal interpolation begins...')
         y[y < 0] = 0.0                                           # in place, optimal_interpolation.py:14
+        tile = self._oi_setting("tile_deg", "OISAT_TILE_DEG", 30.0, float)
+        # averaging() hands back (ny, nx) for the one-month windows run/job.py:77-82 passes and (ny, nx, months[, years])
+        # for longer ones (averaging.py:53-58,:110-114: squeezed 4-D buffers).  The element-wise OI does not care; a
+        # spatial analysis is one analysis per (month, year) slice.
+        outs = [np.full(xa.shape, np.nan) for _ in range(4)]
+        infos = []
+        for tail in np.ndindex(*xa.shape[2:]):
+            sl = (slice(None), slice(None)) + tail
+            res, info = self._oi_spatial(mode, xa[sl], y[sl], np.asarray(Sa)[sl], np.asarray(So)[sl], lat, lon, L, tile,
+                                         unobserved, reg_index, want_error)
+            for o, r in zip(outs, res):
+                o[sl] = r
+            infos.append(info)
+        self.ctm_averaged_vcd_corrected, self.ak_OI, self.increment_OI, self.error_OI = outs
+        self.oi_info = dict(infos[0]) if len(infos) == 1 else {**infos[0], "slices": infos}
+
+    @staticmethod
+    def _oi_spatial(mode, xa, y, Sa, So, lat, lon, L, tile, unobserved, reg_index, want_error):
+        """One (ny, nx) Gaussian-B analysis -> ((Xb, AK, increment, error), info) in the reference's attribute order."""
+        from . import dense
+        from . import optimal_interpolation as oi_mod
         index, scale, curve, found = oi_mod.regularization_pick(Sa, So, reg_index)
         print("The regularization factor is " + str(scale))
         if mode == "dense":
-            xb, inc, info = dense.OI_dense(xa, y, Sa, So, lat, lon, L, scale=scale, want_error=True)
+            xb, inc, info = dense.OI_dense(xa, y, Sa, So, lat, lon, L, scale=scale, want_error=want_error)
         else:
-            tile = self._oi_setting("tile_deg", "OISAT_TILE_DEG", 30.0, float)
-            xb, inc, info = dense.OI_tiled(xa, y, Sa, So, lat, lon, L, tile_deg=tile, scale=scale, want_error=True)
+            xb, inc, info = dense.OI_tiled(xa, y, Sa, So, lat, lon, L, tile_deg=tile, scale=scale, want_error=want_error)
         xb, inc = np.array(xb, dtype=np.float64), np.array(inc, dtype=np.float64)
-        err, ak = np.array(info["err"], dtype=np.float64), np.array(info["ak"], dtype=np.float64)
+        if want_error:
+            err, ak = np.array(info["err"], dtype=np.float64), np.array(info["ak"], dtype=np.float64)
+        else:        # posterior error and averaging kernel cost n m^2 flop (1e16 at 720x1440 / 1e5 obs): skipped on request
+            err, ak = np.full(xb.shape, np.nan), np.full(xb.shape, np.nan)
         # cells the reference's OI gives numbers for: y, So, xa, Sa all non-NaN.  So = +inf there means K = 0 (no weight):
         # the dense analysis simply does not use such an observation, and AK = 0 as in the reference; Sa*reg = 0 makes the
         # reference's AK = 1 - Sb/(Sa*reg) a 0/0 (optimal_interpolation.py:31): mirrored.
         observed = np.isfinite(y) & ~np.isnan(So) & np.isfinite(xa) & np.isfinite(Sa)
-        ak[observed & np.isinf(So)] = 0.0
-        ak[observed & (Sa * scale == 0)] = np.nan
+        if want_error:
+            ak[observed & np.isinf(So)] = 0.0
+            ak[observed & (Sa * scale == 0)] = np.nan
         if unobserved == "nan":
             for a in (xb, inc, err, ak):
                 a[~observed] = np.nan
         else:
-            ak[~observed & np.isfinite(xa)] = 0.0
+            if want_error:
+                ak[~observed & np.isfinite(xa)] = 0.0
             for a in (inc, err, ak):
                 a[~np.isfinite(xa)] = np.nan
-        self.ctm_averaged_vcd_corrected, self.ak_OI, self.increment_OI, self.error_OI = xb, ak, inc, err
-        self.oi_info = {"mode": mode, "corr_length_km": L, "scale": scale, "reg_index": index, "knee_found": found,
-                        "nobs": info["nobs"], "unobserved": unobserved}
+        return (xb, ak, inc, err), {"mode": mode, "corr_length_km": L, "scale": scale, "reg_index": index, "knee_found": found,
+                                    "nobs": info["nobs"], "unobserved": unobserved, "want_error": want_error}
 
     def scaling_factor(self):
         """posterior / prior model column with NaN, inf and 0 mapped to 1.0 -- the field the downstream

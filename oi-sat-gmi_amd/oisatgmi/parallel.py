@@ -100,12 +100,58 @@ def gather_to_root(tensor, dst=0):
     return lst
 
 
-class _DevView:
-    """Zero-copy torch view of memory owned by the C-ABI library (``__cuda_array_interface__``)."""
+class RemoteRankError(RuntimeError):
+    """Another rank failed before the collective; this rank's own work was fine."""
+
+
+_SLAB_DTYPES = ("float16", "bfloat16", "float32", "float64")          # promotion order of what an analysis returns
+
+
+def agree(error=None, device="cpu", dtype=None):
+    """Every rank enters this (tiny) all-reduce BEFORE the data-path collective, also -- especially -- a rank whose own
+    work failed: ``error`` is that rank's exception (or None).  If any rank reports one, every rank raises -- the failing
+    rank its own exception, the others ``RemoteRankError`` -- instead of the healthy ranks blocking in the gather until
+    the RCCL / gloo time-out.  ``dtype`` (optional torch dtype, None for a rank with nothing to send): the ranks also
+    agree on the widest slab dtype, which is returned (None if no rank has one)."""
+    import torch
+    dist = _dist()
+    code = -1 if dtype is None else _SLAB_DTYPES.index(str(dtype).replace("torch.", ""))
+    word = torch.tensor([0 if error is None else 1 + dist.get_rank(), code], dtype=torch.int32, device=device)
+    dist.all_reduce(word, op=dist.ReduceOp.MAX)
+    failed, code = int(word[0]), int(word[1])
+    if error is not None:
+        raise error
+    if failed:
+        raise RemoteRankError(f"rank {failed - 1} failed before the gather (see its own traceback); rank {dist.get_rank()} "
+                              f"stopped with it instead of waiting for a message that will not come")
+    return None if code < 0 else getattr(torch, _SLAB_DTYPES[code])
+
+
+def checked_gather(send, check, dst=0):
+    """``check()`` (e.g. ``MonthTileBatch.check``: waits for the lanes, raises on a failed solve) on every rank, then --
+    only if it passed everywhere -- ONE gather of ``send`` to ``dst``."""
+    err = None
+    try:
+        check()
+    except Exception as e:                                # noqa: BLE001 -- re-raised by agree() on every rank
+        err = e
+    if _dist().get_world_size() > 1:
+        agree(err, send.device)
+    elif err is not None:
+        raise err
+    return gather_to_root(send, dst=dst)
+
+
+class DeviceView:
+    """Zero-copy torch view of memory owned by the C-ABI library (``__cuda_array_interface__``):
+    ``torch.as_tensor(DeviceView(ptr, nelem, "<f4"), device=...)``."""
 
     def __init__(self, ptr, nelem, typestr):
         self.__cuda_array_interface__ = {"shape": (int(nelem),), "typestr": typestr, "data": (int(ptr), False),
                                          "version": 2, "strides": None}
+
+
+_DevView = DeviceView                                     # round-2 name
 
 
 class FieldGather:
@@ -126,7 +172,12 @@ class FieldGather:
     def run(self):
         """xa|inc of this rank's month -> rank 0 (a gather, not an all-gather: nobody else needs them).  The solve
         status of the handle is checked first (one 20-byte read-back), so a failed unchecked run never travels."""
-        self.plan.check()
+        err = None
+        try:
+            self.plan.check()
+        except Exception as e:                            # noqa: BLE001 -- every rank raises, none waits in the gather
+            err = e
+        agree(err, self.send.device)
         dist = _dist()
         parts = [self.slab[r] for r in range(self.world)] if self.rank == 0 else None
         dist.gather(self.send, gather_list=parts, dst=0)
@@ -155,16 +206,24 @@ def analyse_units(units, analyse, weights=None, result_shape=None, dtype=None, d
     shape_of = result_shape if callable(result_shape) else (lambda u: tuple(result_shape))
     numel = [int(np.prod(shape_of(u))) for u in units]
     cap = max(sum(numel[i] for i in part) for part in parts)          # every rank sends a slab of this size
-    got_local = [analyse(units[i]) for i in parts[rank]]
-    if finish is not None:
-        finish()
-    if dtype is None:
-        dtype = got_local[0].dtype if got_local else torch.float32
+    # a rank-local failure (an analysis raising, a failed solve surfacing in finish(), a wrong result shape) must not
+    # leave the other ranks waiting in the gather: collect it, agree, raise everywhere
+    err, got_local = None, []
+    try:
+        got_local = [analyse(units[i]) for i in parts[rank]]
+        if finish is not None:
+            finish()
+        for i, t in zip(parts[rank], got_local):
+            if int(t.numel()) != numel[i]:
+                raise ValueError(f"unit {units[i]!r}: analyse returned {tuple(t.shape)}, expected {shape_of(units[i])}")
+    except Exception as e:                                # noqa: BLE001
+        err = e
+    # slab dtype: the caller's, else the widest any rank produced (a rank with an empty shard has none of its own)
+    agreed = agree(err, device, dtype if dtype is not None else (got_local[0].dtype if got_local else None))
+    dtype = agreed if agreed is not None else torch.float32
     slab = torch.zeros(max(cap, 1), dtype=dtype, device=device)
     off = 0
     for i, t in zip(parts[rank], got_local):
-        if int(t.numel()) != numel[i]:
-            raise ValueError(f"unit {units[i]!r}: analyse returned {tuple(t.shape)}, expected {shape_of(units[i])}")
         slab[off:off + numel[i]] = t.reshape(-1).to(dtype)
         off += numel[i]
     got = gather_to_root(slab, dst=0)                                  # the one collective of the data path

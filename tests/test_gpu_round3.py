@@ -94,3 +94,99 @@ def test_interpolator_type2_gathers_through_the_same_ties(ctx, golden):
     r2o = orc.interpolator(2, 1.0, s, ctm, 0.0, record_type=cfg.satellite_opt)
     check_l3_record(g, "MOPITT", grid, 4, r2, 1e-12)
     np.testing.assert_allclose(r2.vcd, r2o.vcd, rtol=1e-12, equal_nan=True)
+
+
+# ------------------------------------------------------------------------------------------------
+# oisatgmi.oi() in the spatial modes on what average() really hands over (driver.py:53-63,:108-114)
+# ------------------------------------------------------------------------------------------------
+class _Reader:
+    def __init__(self, sat_data):
+        self.sat_data = sat_data
+
+
+def _month_of_granules(ny, nx, k, seed, months=(6,)):
+    out = []
+    for mth in months:
+        out += syn.granule_stack(ny, nx, k, seed + mth, year=2019, month=mth, with_none=True, coverage=0.12)
+    return out
+
+
+def _facade(ny, nx, k, seed, months, mode, **attrs):
+    from oisatgmi.driver import oisatgmi
+    o = oisatgmi()
+    o.reader_obj = _Reader(_month_of_granules(ny, nx, k, seed, months))
+    o.oi_mode, o.corr_length_km, o.tile_deg = mode, 500.0, 45.0
+    for k_, v in attrs.items():
+        setattr(o, k_, v)
+    return o
+
+
+@pytest.mark.parametrize("mode", ["dense", "tiled"])
+def test_oi_spatial_modes_after_average_one_month(ctx, mode):
+    """reader records -> average() -> oi(): the one-month window run/job.py:77-82 passes gives (ny, nx) fields; the
+    spatial modes analyse them on the grid of the first granule and fill the four attributes of driver.py:110-114."""
+    ny, nx = 36, 72
+    o = _facade(ny, nx, 4, 8100, (6,), mode)
+    o.average("2019-06-01", "2019-07-01", gasname="NO2")
+    assert o.ctm_averaged_vcd.shape == (ny, nx)
+    o.oi("OMI", error_ctm=50.0)
+    xa, y, se = o.ctm_averaged_vcd, o.sat_averaged_vcd, o.sat_averaged_error
+    observed = np.isfinite(y) & ~np.isnan(se) & np.isfinite(xa)
+    assert observed.sum() > 200 and o.oi_info["nobs"] == int((observed & np.isfinite(se)).sum())
+    for a in (o.ctm_averaged_vcd_corrected, o.ak_OI, o.increment_OI, o.error_OI):
+        assert a.shape == (ny, nx) and a.dtype == np.float64
+        assert np.isnan(a[~observed]).all() and np.isfinite(a[observed]).all()
+    if mode == "dense":                 # the global analysis against the float64 oracle, error fields included
+        lat, lon = syn.global_grid(ny, nx)
+        use = observed & np.isfinite(se)
+        cell = np.flatnonzero(use.ravel())
+        s = o.oi_info["scale"]
+        ref = orc.dense_oi(lat, lon, np.where(np.isfinite(xa), xa, 0.0), np.where(np.isfinite(xa), (0.5 * xa) ** 2, 0.0),
+                           lat.ravel()[cell], lon.ravel()[cell], cell, y.ravel()[cell], se.ravel()[cell] ** 2, 500.0, scale=s,
+                           want_error=True)
+        fs = np.nanmax(np.abs(xa))
+        assert np.abs(o.ctm_averaged_vcd_corrected.ravel()[cell] - ref["xa"][cell]).max() <= 1e-5 * fs
+        assert np.abs(o.increment_OI.ravel()[cell] - ref["inc"][cell]).max() <= 1e-5 * fs
+        np.testing.assert_allclose(o.error_OI.ravel()[cell], ref["err"][cell], rtol=2e-3, atol=1e-4 * fs)
+        np.testing.assert_allclose(o.ak_OI.ravel()[cell], ref["ak_obs"], rtol=0, atol=2e-4)
+
+
+@pytest.mark.parametrize("mode", ["dense", "tiled"])
+def test_oi_spatial_modes_after_average_two_months(ctx, mode):
+    """A two-month window: averaging() returns (ny, nx, 2) (averaging.py:53-58,:110-114; only the last month is reduced,
+    the quirk of :97) and oi() runs one spatial analysis per month slice instead of tripping over the extra axis."""
+    ny, nx = 36, 72
+    o = _facade(ny, nx, 3, 8200, (6, 7), mode, oi_unobserved="xa")
+    o.average("2019-06-01", "2019-08-01", gasname="NO2")
+    assert o.ctm_averaged_vcd.shape == (ny, nx, 2)
+    o.oi("OMI", error_ctm=50.0)
+    assert len(o.oi_info["slices"]) == 2 and o.oi_info["slices"][0]["nobs"] == 0 and o.oi_info["slices"][1]["nobs"] > 200
+    for a in (o.ctm_averaged_vcd_corrected, o.ak_OI, o.increment_OI, o.error_OI):
+        assert a.shape == (ny, nx, 2)
+    # the month that was reduced equals the one-month run of the same granules
+    o1 = _facade(ny, nx, 3, 8200, (6, 7), mode, oi_unobserved="xa")
+    o1.average("2019-07-01", "2019-08-01", gasname="NO2")
+    o1.oi("OMI", error_ctm=50.0)
+    for name in ("ctm_averaged_vcd_corrected", "ak_OI", "increment_OI", "error_OI"):
+        np.testing.assert_array_equal(getattr(o, name)[:, :, 1], getattr(o1, name))
+    # a grid that does not match the fields is refused with a clear message
+    o1.grid_lat, o1.grid_lon = syn.global_grid(18, 36)
+    with pytest.raises(ValueError, match="grid is"):
+        o1.oi("OMI", error_ctm=50.0)
+
+
+def test_oi_posterior_error_is_optional(ctx, monkeypatch):
+    """OISAT_OI_ERROR=0 / oi_want_error=False: the n m^2-flop posterior error and averaging kernel are skipped (NaN),
+    analysis and increment are unchanged."""
+    ny, nx = 36, 72
+    a = _facade(ny, nx, 4, 8100, (6,), "dense")
+    a.average("2019-06-01", "2019-07-01")
+    a.oi("OMI")
+    monkeypatch.setenv("OISAT_OI_ERROR", "0")
+    b = _facade(ny, nx, 4, 8100, (6,), "dense")
+    b.average("2019-06-01", "2019-07-01")
+    b.oi("OMI")
+    assert b.oi_info["want_error"] is False and a.oi_info["want_error"] is True
+    np.testing.assert_array_equal(a.ctm_averaged_vcd_corrected, b.ctm_averaged_vcd_corrected)
+    np.testing.assert_array_equal(a.increment_OI, b.increment_OI)
+    assert np.isnan(b.error_OI).all() and np.isnan(b.ak_OI).all() and np.isfinite(a.error_OI).any()

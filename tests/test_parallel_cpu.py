@@ -166,6 +166,79 @@ def test_no_collective_inside_the_unit_loop():
     assert wall >= 8 * unit_s * 0.98
 
 
+def _failing_worker(rank, world, port, q):
+    import time
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = {}
+    try:
+        # (1) one rank's analysis raises: EVERY rank leaves analyse_units with an error, quickly
+        def analyse(u):
+            if u == 3:
+                raise FloatingPointError("non-positive pivot in unit 3")
+            return torch.full((2, 2), float(u))
+        t0 = time.perf_counter()
+        try:
+            parallel.analyse_units(range(4), analyse, result_shape=(2, 2), dtype=torch.float32)
+            out["units"] = "no error"
+        except FloatingPointError:
+            out["units"] = "own"
+        except parallel.RemoteRankError as e:
+            out["units"] = "remote:" + str(e)[:6]
+        # (2) the failure surfaces in finish() (a failed asynchronous solve) on the other rank
+        def finish():
+            if rank == 0:
+                raise RuntimeError("solve status: time-out")
+        try:
+            parallel.analyse_units(range(4), lambda u: torch.zeros(3), result_shape=(3,), dtype=torch.float32, finish=finish)
+            out["finish"] = "no error"
+        except parallel.RemoteRankError:
+            out["finish"] = "remote"
+        except RuntimeError:
+            out["finish"] = "own"
+        # (3) checked_gather: check() fails on rank 1 only
+        def check():
+            if rank == 1:
+                raise RuntimeError("lane 3: not positive definite")
+        try:
+            parallel.checked_gather(torch.zeros(4), check)
+            out["gather"] = "no error"
+        except parallel.RemoteRankError:
+            out["gather"] = "remote"
+        except RuntimeError:
+            out["gather"] = "own"
+        # (4) and the group is still usable afterwards: a clean run, rank 1's shard EMPTY and no dtype given --
+        # the slab dtype is agreed across ranks (float64 from rank 0's results), not defaulted per rank
+        res = parallel.analyse_units(["only"], lambda u: torch.full((2,), 7.0, dtype=torch.float64), result_shape=(2,))
+        out["after"] = (rank != 0 and res is None) or (rank == 0 and res[0].dtype == torch.float64 and float(res[0][1]) == 7.0)
+        out["seconds"] = time.perf_counter() - t0
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_failing_rank_stops_every_rank_instead_of_hanging_the_gather():
+    """a rank-local exception right before the only collective used to leave the other ranks blocked in
+    dist.gather until the backend's time-out.  Now every rank enters a status all-reduce first and all of them raise."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(60)                                       # far below any collective time-out
+        assert p.exitcode == 0
+    got = dict(q.get(timeout=10) for _ in range(2))
+    owner3 = parallel.owner_of(4, 2)[3]
+    assert got[owner3]["units"] == "own" and got[1 - owner3]["units"].startswith("remote")
+    assert got[0]["finish"] == "own" and got[1]["finish"] == "remote"
+    assert got[1]["gather"] == "own" and got[0]["gather"] == "remote"
+    assert got[0]["after"] and got[1]["after"]
+    assert max(g["seconds"] for g in got.values()) < 20
+
+
 def test_shards_come_back_heaviest_first_and_ragged_results_gather():
     w = [3.0, 9.0, 1.0, 27.0, 2.0]
     parts = parallel.partition_units(5, 2, w)
