@@ -65,6 +65,8 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--tier-a-only", action="store_true", help="run only the reference-parity (Tier-A) kernel legs (profiling aid)")
+    ap.add_argument("--only", default="", help="profiling aid: comma list of legs to run INSTEAD of the whole bench -- tiled, "
+                    "secondary (config 2 alone), config4; prints {leg: result}")
     ap.add_argument("--no-config4", action="store_true", help="skip the fixed-workload strong-scaling leg (12 months x tiles)")
     ap.add_argument("--c4-months", type=int, default=12)
     ap.add_argument("--c4-passes", type=int, default=2)
@@ -623,6 +625,30 @@ def main():
     n = ny * nx
     if args.tier_a_only:
         print(json.dumps({"tier_a": tier_a_leg(ctx, ny, nx, nobs, sync), "tier_a_kernels": tier_a_kernels_leg(ctx, sync)}))
+        return
+    if args.only:
+        if world != 1:
+            raise SystemExit("--only is a single-GPU profiling aid")
+        res = {}
+        for leg in args.only.split(","):
+            if leg == "tiled":
+                res[leg] = tiled_leg(ctx, args.workload, sync)
+            elif leg == "secondary":
+                ny2, nx2, _, L2, _, r2 = WORKLOADS[SECONDARY]
+                plan2 = make_plan(ctx, SECONDARY, 4000)
+                plan2.run(L2, refine=r2, check_pd=True)
+                el2 = time_steps(lambda: plan2.run(L2, refine=r2), 20, 3, sync)
+                el1 = time_steps(lambda: plan2.run(L2, refine=1), 20, 3, sync)
+                roof2, per2 = roofline_leg(ctx, plan2, L2, r2, 5)
+                res[leg] = {"ms_per_step": 1e3 * el2 / 20, "ms_per_step_refine1": 1e3 * el1 / 20, "refine": r2, "obs": plan2.m,
+                            "roofline": roof2, "kernel_ms_per_step": per2}
+                del plan2
+            elif leg == "config4":
+                lat2, lon2 = syn.global_grid(ny, nx)
+                res[leg] = config4_leg(ctx, args, 1, 0, local, lat2, lon2, sync, None)
+            else:
+                raise SystemExit(f"--only: unknown leg {leg!r}")
+        print(json.dumps(res))
         return
     # ---- shared grid: built on rank 0, broadcast once (RCCL) -------------------------------------
     lat2, lon2 = syn.global_grid(ny, nx)

@@ -64,6 +64,10 @@ int oisat_wait_for(oisat_ctx* waiter, oisat_ctx* signaler); /* work enqueued on 
                                                                when everything enqueued on signaler's stream so far is
                                                                done (event record + stream wait; nothing blocks the host) */
 int oisat_sync(oisat_ctx* h);                               /* hipStreamSynchronize(stream) */
+int oisat_query(oisat_ctx* h, int* busy);                   /* hipStreamQuery(stream): *busy = 1 while work is in flight;
+                                                               lets a host that drives several handles serve whichever
+                                                               finishes first (BatchedFactor: a group's solves are released
+                                                               when THAT group is factored, whatever the enqueue order) */
 int oisat_dmalloc(oisat_ctx* h, size_t bytes, void** dev_out);
 int oisat_dfree(oisat_ctx* h, void* dev);
 int oisat_h2d(oisat_ctx* h, void* dev_dst, const void* host_src, size_t bytes);   /* async on stream */
@@ -301,8 +305,12 @@ int oisat_potrs(oisat_ctx* h, const float* L, int64_t m, int64_t ld, double* z_i
 int oisat_cov_residual(oisat_ctx* h, const double* oxyz, const double* osig, const double* ovar, int64_t m,
                        double g, const double* d, const double* z, double* r_out, const double* olat_sorted);
 
-/* Solve (H B H^T + R) z = d: potrs + `refine` rounds of double-residual refinement.
- * resid_host (may be NULL): relative residual norms, refine+1 entries. */
+/* Solve (H B H^T + R) z = d with the fp32 factor as a preconditioner: z = M^-1 d, then at most `refine` rounds of
+ * { r = d - S z in float64; stop if |r| <= tol |d|; z += M^-1 r }.  The stopping test runs on the device (the launches of
+ * the rounds after convergence return at once; nothing waits for the host).  tol: oisat_set_refine_tol, default 1e-6
+ * (the increment is K r away from the exact one and |K| <= 1: fields within 1e-6 |d|); 0 = always run every round.
+ * resid_host (may be NULL): relative residual norms before each round and after the last, refine+1 entries; rounds that
+ * were not run repeat the last computed value.  Synchronises only when resid_host is given. */
 int oisat_gain_solve(oisat_ctx* h, const float* L, const double* oxyz, const double* osig, const double* ovar,
                      int64_t m, int64_t ld, double g, const double* d, int refine, double* z_out,
                      double* resid_host, const double* olat_sorted /* as for oisat_cov_residual; may be NULL */);
@@ -333,6 +341,17 @@ int oisat_posterior_error(oisat_ctx* h, const float* L, int64_t m, int64_t ld, c
  * (the dense counterpart of AK = 1 - Sb/(Sa*reg), optimal_interpolation.py:31).  ak_out: dev double[m]. */
 int oisat_gain_diag(oisat_ctx* h, const float* L, int64_t m, int64_t ld, const double* ovar, int64_t chunk_rows,
                     double* ak_out);
+
+/* How a handle's batched factorization shares the GPU with other handles' work that runs at the same time (several
+ * groups of systems factored side by side, oisatgmi/dense.py BatchedFactor): wave_prio 0..3 = s_setprio of its kernels'
+ * waves -- where waves of two groups sit on one SIMD the arbiter serves the higher one first, so the group with the
+ * longest dependent chain (the polar caps of a localised month) is not slowed by the other group's bulk GEMMs;
+ * gemm_wg_per_cu 1 | 2 (0 = default 2) = workgroups per CU of its persistent GEMM launches, 1 leaves a slot on every CU
+ * to the other group.  Results do not depend on either. */
+int oisat_set_share(oisat_ctx* h, int wave_prio, int gemm_wg_per_cu);
+
+/* Relative residual |d - S z| / |d| at which oisat_gain_solve stops refining on this handle (default 1e-6; 0: never). */
+int oisat_set_refine_tol(oisat_ctx* h, double tol);
 
 /* ---- batched factorization: many independent systems in lock-step ---------------------------------------------------
  * The tiles of a localised analysis (and the months of a batch) are small systems -- 4,000-18,000 observations -- whose

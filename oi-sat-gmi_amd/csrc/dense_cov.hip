@@ -90,9 +90,11 @@ __device__ __forceinline__ int64_t lower_bound_lat(const double* __restrict__ a,
 __global__ __launch_bounds__(256) void cov_residual_kernel(const double* __restrict__ oxyz, const double* __restrict__ osig,
                                                             const double* __restrict__ ovar, int64_t m, double g,
                                                             const double* __restrict__ d, const double* __restrict__ z,
-                                                            double* __restrict__ r, const double* __restrict__ olat, double win_deg) {
+                                                            double* __restrict__ r, const double* __restrict__ olat, double win_deg,
+                                                            const int* __restrict__ converged) {
     __shared__ double sx[256], sy[256], sz[256], sw[256];      // chunk of 256 columns: coords and sig*z
     __shared__ double part[4][64];
+    if (converged != nullptr && *converged != 0) return;       // the refinement has met its tolerance: nothing left to evaluate
     const int t = threadIdx.x;
     const int lr = t & 63, ph = t >> 6;
     const int64_t row = (int64_t)blockIdx.x * 64 + lr;
@@ -242,13 +244,18 @@ extern "C" int oisat_innovation(oisat_ctx* h, int dtype, const void* xb, const i
     return OISAT_OK;
 }
 
-extern "C" int oisat_cov_residual(oisat_ctx* h, const double* oxyz, const double* osig, const double* ovar, int64_t m, double g,
-                                  const double* d, const double* z, double* r_out, const double* olat_sorted) {
+int oisat_cov_residual_if(oisat_ctx* h, const double* oxyz, const double* osig, const double* ovar, int64_t m, double g,
+                          const double* d, const double* z, double* r_out, const double* olat_sorted, const int* converged_dev) {
     ARG_CHECK(h && oxyz && osig && ovar && d && z && r_out && m > 0);
     const double win = lat_window_deg(g * (double)kLog2e);
     OISAT_LAUNCH(h, "cov_residual", cov_residual_kernel, dim3((unsigned)cdiv(m, 64)), dim3(256), 0, oxyz, osig, ovar, m, g, d,
-                 z, r_out, win < 180.0 ? olat_sorted : (const double*)nullptr, win);
+                 z, r_out, win < 180.0 ? olat_sorted : (const double*)nullptr, win, converged_dev);
     return OISAT_OK;
+}
+
+extern "C" int oisat_cov_residual(oisat_ctx* h, const double* oxyz, const double* osig, const double* ovar, int64_t m, double g,
+                                  const double* d, const double* z, double* r_out, const double* olat_sorted) {
+    return oisat_cov_residual_if(h, oxyz, osig, ovar, m, g, d, z, r_out, olat_sorted, nullptr);
 }
 
 extern "C" int oisat_apply_increment(oisat_ctx* h, int dtype, const double* gxyz, const double* gsig, int64_t n,

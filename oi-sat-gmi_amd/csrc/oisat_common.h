@@ -67,8 +67,8 @@ struct oisat_ctx {
     std::vector<ProfPending> pending;
     std::vector<hipEvent_t> free_events;
     // grow-only device workspaces (never freed/reallocated inside a timed region once warm)
-    void* ws[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t ws_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    void* ws[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t ws_bytes[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // last scaling sweep uploaded into workspace slot 0 (oi_diag.hip)
     double scales_host[OISAT_MAX_SCALES] = {0};
     int scales_n = 0;
@@ -76,6 +76,9 @@ struct oisat_ctx {
     // the factor left by the last oisat_potrf on this handle (dense_chol.hip)
     ChFactor factor;
     bool small_tiles = true;            // gemm_nt: 64x64 tiles for launches of <= 700 128x128 tiles (latency-bound ones)
+    double refine_tol = 1e-6;           // oisat_set_refine_tol: relative residual at which the gain solve stops refining
+    int wave_prio = 0;                  // oisat_set_share: s_setprio of this handle's batched factorization kernels (0..3)
+    int gemm_wg_per_cu = 0;             // oisat_set_share: workgroups per CU of its persistent GEMM launches (0 = default, 2)
     hipStream_t own_stream = nullptr;   // created by oisat_stream_create, destroyed at shutdown
     hipStream_t aux_stream = nullptr;   // look-ahead Cholesky: trailing updates run here, the panel chain on `stream`
     std::vector<hipEvent_t> sync_events;

@@ -51,7 +51,7 @@ extern "C" void oisat_shutdown(oisat_ctx* h) {
         (void)hipEventDestroy(p.b);
     }
     for (auto ev : h->free_events) (void)hipEventDestroy(ev);
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 10; ++i)
         if (h->ws[i]) (void)hipFree(h->ws[i]);
     if (h->pinned) (void)hipHostFree(h->pinned);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -106,6 +106,17 @@ extern "C" int oisat_wait_for(oisat_ctx* waiter, oisat_ctx* signaler) {
 extern "C" int oisat_sync(oisat_ctx* h) {
     ARG_CHECK(h != nullptr);
     HIP_TRY(hipStreamSynchronize(h->stream));
+    return OISAT_OK;
+}
+
+extern "C" int oisat_query(oisat_ctx* h, int* busy) {
+    ARG_CHECK(h != nullptr && busy != nullptr);
+    const hipError_t e = hipStreamQuery(h->stream);
+    if (e != hipSuccess && e != hipErrorNotReady) {
+        oisat_set_error("hipStreamQuery failed: %s", hipGetErrorString(e));
+        return OISAT_EHIP;
+    }
+    *busy = e == hipErrorNotReady ? 1 : 0;
     return OISAT_OK;
 }
 

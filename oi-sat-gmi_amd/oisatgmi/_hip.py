@@ -32,6 +32,9 @@ SIGNATURES = {
     "oisat_stream_create": (C.c_int, [_c_ctx]),
     "oisat_bind_thread": (C.c_int, [_c_ctx]),
     "oisat_wait_for": (C.c_int, [_c_ctx, _c_ctx]),
+    "oisat_query": (C.c_int, [_c_ctx, C.POINTER(C.c_int)]),
+    "oisat_set_share": (C.c_int, [_c_ctx, C.c_int, C.c_int]),
+    "oisat_set_refine_tol": (C.c_int, [_c_ctx, C.c_double]),
     "oisat_sync": (C.c_int, [_c_ctx]),
     "oisat_dmalloc": (C.c_int, [_c_ctx, C.c_size_t, C.POINTER(_ptr)]),
     "oisat_dfree": (C.c_int, [_c_ctx, _ptr]),
@@ -306,6 +309,12 @@ class Context:
 
     def sync(self):
         self.check(self.lib.oisat_sync(self.h))
+
+    def busy(self) -> bool:
+        """True while work enqueued on this handle's stream is still in flight (``hipStreamQuery``)."""
+        b = C.c_int(0)
+        self.check(self.lib.oisat_query(self.h, C.byref(b)))
+        return bool(b.value)
 
     def alloc(self, nbytes: int) -> DeviceBuffer:
         return DeviceBuffer(self, nbytes)

@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import time
 
 import numpy as np
 
@@ -25,6 +26,9 @@ from . import _hip
 
 EARTH_RADIUS_KM = 6371.0
 NB = 128                      # Cholesky block edge (csrc/dense_chol.hip)
+# relative float64 residual |d - S z| / |d| at which the gain solve stops refining (oisat_gain_solve): the increment is K r
+# away from the exact one and |K| <= 1, so the fields are then within 1e-6 |d| -- a tenth of the 1e-5 bar
+REFINE_TOL = float(os.environ.get("OISAT_REFINE_TOL", "1e-6"))
 
 
 def unit_vectors(lat_deg, lon_deg) -> np.ndarray:
@@ -159,8 +163,11 @@ class DenseAnalysis:
         c.upload_into(self.oy.ptr, np.ravel(obs_y)[o], dtype=np.float64)
 
     # ---- the hot path: everything below runs on the device, enqueued on the handle's stream
-    def run(self, L_km: float, refine: int = 2, check_pd: bool = False, want_resid: bool = False):
+    def run(self, L_km: float, refine: int = 2, check_pd: bool = False, want_resid: bool = False, tol=None):
+        """``refine``: the most refinement rounds the gain solve may take; it stops earlier once the float64 residual is
+        below ``tol`` |d| (default: the handle's, 1e-6 -- ``oisat_set_refine_tol``; 0 runs every round)."""
         c, lib, h = self.ctx, self.ctx.lib, self.ctx.h
+        c.check(lib.oisat_set_refine_tol(h, REFINE_TOL if tol is None else float(tol)))      # per run: handles are shared
         m, ld = self.m, self.mp
         g = self._g = decay_constant(L_km)
         item = self.dt.itemsize
@@ -185,7 +192,7 @@ class DenseAnalysis:
             c.check(lib.oisat_innovation(h, self.code, self.xb_ptr, self.ocell.ptr, self.oy.ptr, self.m, self.d.ptr))
         c.check(lib.oisat_cov_build(h, self.oxyz.ptr, self.osig.ptr, self.ovar.ptr, self.m, g, self.S.ptr, self.mp))
 
-    def run_solve(self, refine: int = 2):
+    def run_solve(self, refine: int = 2, tol=None):
         if self.tinv is None:
             raise ValueError("run_build / run_solve belong to plans created with batched=True (they own their inverted "
                              "diagonal blocks); use run() for a plan that factors on its own handle")
@@ -193,6 +200,7 @@ class DenseAnalysis:
         m, ld, g = self.m, self.mp, self._g
         item = self.dt.itemsize
         xb, xa, inc = self.xb_ptr, self.out_ptr, self.out_ptr + self.n * item
+        c.check(lib.oisat_set_refine_tol(h, REFINE_TOL if tol is None else float(tol)))
         c.check(lib.oisat_factor_adopt(h, self.S.ptr, m, ld, self.tinv.ptr))
         c.check(lib.oisat_gain_solve(h, self.S.ptr, self.oxyz.ptr, self.osig.ptr, self.ovar.ptr, m, ld, g, self.d.ptr,
                                      int(refine), self.z.ptr, None, self.olat.ptr))
@@ -298,13 +306,26 @@ class BatchedFactor:
             cur.append(p)
         if cur:
             groups.append(cur)
-        self.groups = groups[::-1]                          # smallest systems first
+        # enqueue order (OISAT_BATCH_ORDER): "largest" (default) -- the group with the longest dependent chain first: in a
+        # 720x1440 month the two polar caps (137 diagonal blocks each) are the critical path and used to sit idle for
+        # 9 ms of a 73 ms span behind the tile group's first launches (profiles/r02_e_tiled_phases.txt); "smallest" is
+        # round 2's order.  Whatever the order, a group's solves are released when THAT group is factored (run() polls).
+        self.order = os.environ.get("OISAT_BATCH_ORDER", "largest")
+        self.groups = groups if self.order == "largest" else groups[::-1]
         # schedule (OISAT_BATCH_SCHEDULE): "overlap" (default) -- one stream per group, all groups side by side;
         # "sequential" -- the groups one after the other (each one's dependent chain then runs at its isolated speed and
-        # its solves go underneath the next group's factorization).  Either way a group's solves start when THAT group
-        # is factored.
+        # its solves go underneath the next group's factorization).
         self.schedule = os.environ.get("OISAT_BATCH_SCHEDULE", "overlap")
         self.ctxs = [_hip.Context(device).own_stream() for _ in self.groups]
+        # sharing (oisat_set_share): the group with the longest chain is the critical path of the whole batch -- its waves
+        # get priority on the SIMDs they share with the other groups' GEMMs, and the other groups' persistent GEMM launches
+        # leave one workgroup slot per CU free (OISAT_BATCH_MAJOR_PRIO 0..3, OISAT_BATCH_MINOR_WG 1 | 2)
+        if len(self.groups) > 1:
+            major = max(range(len(self.groups)), key=lambda gi: self.groups[gi][0].mp)
+            mprio = int(os.environ.get("OISAT_BATCH_MAJOR_PRIO", "3"))
+            mwg = int(os.environ.get("OISAT_BATCH_MINOR_WG", "2"))
+            for gi, ctx in enumerate(self.ctxs):
+                ctx.check(ctx.lib.oisat_set_share(ctx.h, mprio if gi == major else 0, 2 if gi == major else mwg))
         self.ids = []
         for g, ctx in zip(self.groups, self.ctxs):
             n = len(g)
@@ -316,32 +337,58 @@ class BatchedFactor:
             ctx.check(ctx.lib.oisat_batch_create(ctx.h, n, Sp, mm, ld, Tp, C.byref(bid)))
             self.ids.append(bid.value)
         self.group_of = {id(p): gi for gi, g in enumerate(self.groups) for p in g}
+        self._threads = None
         # measured, one box (1 month of 720x1440 / 1e5 obs; a rank's eighth of 12 months; all 12 months):
         # overlap 73.6 / 112 / 745 ms, sequential 77.0 / 119 / 746 ms
 
     def run(self, pool, per_lane_plans, refine, check_pd=False):
         """``per_lane_plans[li]``: the plans of lane li in run order, already BUILT (their S enqueued on the lane).
 
-        Every group's factorization is enqueued at once; the HOST then waits group by group (smallest systems first)
-        and enqueues that group's solves on the lanes -- it returns when the last group is factored and its solves
-        are enqueued.  (A device-side wait would park a barrier packet at the head of every lane's hardware queue for
+        Every group's factorization is enqueued at once; the HOST then waits for the groups in completion order
+        and enqueues each group's solves on the lanes as it finishes -- it returns when the last group is factored and its
+        solves are enqueued.  (A device-side wait would park a barrier packet at the head of every lane's hardware queue for
         the whole factorization, and the command processor polls parked queues at the expense of the running one:
         with 12 parked lanes every kernel of the dependent chain took 40-60 us longer in the rocprofv3 trace --
         potrf_diag 27 -> 64, the panel TRSM 17 -> 80 us -- a third of a polar cap's factorization time.)"""
         sequential = self.schedule == "sequential"
-        prev = None
-        for gi, (g, ctx, bid) in enumerate(zip(self.groups, self.ctxs, self.ids)):
+
+        def enqueue_group(gi):
+            g, ctx, bid = self.groups[gi], self.ctxs[gi], self.ids[gi]
+            ctx.bind_thread()
             for lane in {id(p.ctx): p.ctx for p in g}.values():
                 ctx.wait_for(lane)                          # short: the builds are a few ms
-            if sequential and prev is not None:
-                ctx.wait_for(prev)                          # one parked queue
+            if sequential and gi > 0:
+                ctx.wait_for(self.ctxs[gi - 1])             # one parked queue
             info = (C.c_int * 2)(0, -1)
             ctx.check(ctx.lib.oisat_batch_potrf(ctx.h, bid, info if check_pd else None))
-            prev = ctx
-        for gi, ctx in enumerate(self.ctxs):
-            ctx.sync()
-            pool.enqueue([[(lambda p=p: p.run_solve(refine)) for p in plans if self.group_of[id(p)] == gi]
-                          for plans in per_lane_plans])
+
+        # One enqueueing host thread per group: a polar-cap factorization is ~700 launches = 20-25 ms of host time inside
+        # ONE library call, and a single thread enqueued the groups one after the other -- whichever group came second
+        # started that much later (round 2: the caps at 10 ms behind the tiles; caps first: the tiles at 25 ms).
+        if len(self.groups) > 1 and not sequential and not check_pd:
+            if self._threads is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._threads = ThreadPoolExecutor(max_workers=len(self.groups), thread_name_prefix="oisat-group")
+            futures = [self._threads.submit(enqueue_group, gi) for gi in range(len(self.groups))]
+        else:
+            futures = []
+            for gi in range(len(self.groups)):
+                enqueue_group(gi)
+        # release each group's solves as soon as it is factored, in COMPLETION order: poll the group streams
+        pending = list(range(len(self.ctxs)))
+        while pending:
+            done = [gi for gi in pending if (not futures or futures[gi].done()) and not self.ctxs[gi].busy()]
+            if not done:
+                time.sleep(2e-5)
+                continue
+            for gi in done:
+                if futures and futures[gi].exception() is not None:
+                    for f in futures:
+                        f.exception()                       # let every enqueueing thread finish before raising
+                    raise futures[gi].exception()
+                pending.remove(gi)
+                pool.enqueue([[(lambda p=p: p.run_solve(refine)) for p in plans if self.group_of[id(p)] == gi]
+                              for plans in per_lane_plans])
 
     def check(self, what="batched factorization"):
         errors = []
@@ -354,6 +401,9 @@ class BatchedFactor:
             raise _hip.OisatError("; ".join(errors))
 
     def close(self):
+        if self._threads is not None:
+            self._threads.shutdown(wait=True)
+            self._threads = None
         for ctx, bid in zip(self.ctxs, self.ids):
             if ctx.h is not None:
                 ctx.lib.oisat_batch_destroy(ctx.h, bid)
@@ -732,7 +782,7 @@ class MonthTileBatch:
         self.pool.close()
 
 
-def OI_dense(Xa, Y, Sa, So, lat, lon, L_km, scale=1.0, refine=2, obs=None, dtype=None, want_error=False):
+def OI_dense(Xa, Y, Sa, So, lat, lon, L_km, scale=1.0, refine=2, obs=None, dtype=None, want_error=False, tol=None):
     """Dense-covariance analysis with the reference's gridded argument convention.
 
     ``Xa, Sa``: (ny, nx) background and its variance; ``Y, So``: (ny, nx) observations and their
@@ -768,7 +818,7 @@ def OI_dense(Xa, Y, Sa, So, lat, lon, L_km, scale=1.0, refine=2, obs=None, dtype
     sa_f = np.where(np.isfinite(Sa), Sa, 0.0)
     plan.load_background(xa_f, sa_f, scale=scale)
     plan.load_obs(olat, olon, cell, oy, ovar)
-    resid = plan.run(L_km, refine=refine, check_pd=True, want_resid=True)
+    resid = plan.run(L_km, refine=refine, check_pd=True, want_resid=True, tol=tol)
     xb, inc = plan.download()
     extra = {}
     if want_error:                     # the other two members of OI's 4-tuple: averaging kernel and sqrt(Sb)

@@ -190,3 +190,42 @@ def test_oi_posterior_error_is_optional(ctx, monkeypatch):
     np.testing.assert_array_equal(a.ctm_averaged_vcd_corrected, b.ctm_averaged_vcd_corrected)
     np.testing.assert_array_equal(a.increment_OI, b.increment_OI)
     assert np.isnan(b.error_OI).all() and np.isnan(b.ak_OI).all() and np.isfinite(a.error_OI).any()
+
+
+# ------------------------------------------------------------------------------------------------
+# the gain solve stops refining when the float64 residual meets its tolerance (device-side test)
+# ------------------------------------------------------------------------------------------------
+def test_refinement_stops_at_its_tolerance(ctx):
+    """oisat_gain_solve: at most `refine` rounds of { r = d - S z; stop if |r| <= tol |d|; z += M^-1 r }.  tol = 0 runs every
+    round (residual down to rounding), the default 1e-6 stops as soon as it is met -- the reported list then repeats the
+    last computed residual -- and a tolerance the plain solve already meets applies no correction at all.  The fields of
+    the three agree far inside the 1e-5 bar, and with the float64 oracle."""
+    from oisatgmi import dense
+    p = syn.point_obs_case(90, 180, 3000, 7301, swaths=True)
+    cell = dense.regular_grid_cell(p.lat, p.lon, p.obs_lat, p.obs_lon)
+    y = np.where(p.obs_y < 0, 0, p.obs_y)
+    L = 500.0
+    plan = dense.DenseAnalysis(p.lat, p.lon, max_obs=3000, dtype=np.float32)
+    plan.load_background(p.Xa, p.Sa)
+    plan.load_obs(p.obs_lat, p.obs_lon, cell, y, p.obs_var)
+    out = {}
+    for name, tol in (("all", 0.0), ("default", None), ("none", 0.5)):
+        resid = plan.run(L, refine=3, check_pd=True, want_resid=True, tol=tol)
+        xa, inc = plan.download()
+        out[name] = (resid, xa.copy(), plan.download_z())
+        plan.run(L, refine=3, tol=tol)                          # the asynchronous path takes the same decisions
+        xa2, _ = plan.download()
+        np.testing.assert_array_equal(xa, xa2)
+    r_all, r_def, r_none = out["all"][0], out["default"][0], out["none"][0]
+    assert len(r_all) == len(r_def) == len(r_none) == 4
+    assert r_all[0] > 1e-8 and r_all[-1] < 1e-11 and all(b < a for a, b in zip(r_all[:2], r_all[1:3]))
+    assert r_all[0] == r_def[0] == r_none[0]                     # same plain solve
+    k = next(i for i, r in enumerate(r_def) if r <= dense.REFINE_TOL)
+    assert 1 <= k <= 2 and r_def[:k + 1] == r_all[:k + 1] and all(r == r_def[k] for r in r_def[k:])
+    assert all(r == r_none[0] for r in r_none)                  # 0.5 |d| is met at once: no correction applied
+    ref = orc.dense_oi(p.lat, p.lon, p.Xa, p.Sa, p.obs_lat, p.obs_lon, cell, y, p.obs_var, L)
+    scale = np.abs(ref["xa"]).max()
+    assert np.abs(out["default"][1].ravel() - ref["xa"]).max() <= 1e-5 * scale
+    assert np.abs(out["default"][1] - out["all"][1]).max() <= 1e-6 * scale
+    dz = np.abs(out["default"][2] - out["all"][2]).max() / np.abs(out["all"][2]).max()
+    assert dz <= 1e-4, dz
