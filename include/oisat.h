@@ -56,6 +56,11 @@ int oisat_device_info(oisat_ctx* h, char* name_out, int name_cap, int* cu_count,
 int oisat_set_stream(oisat_ctx* h, void* hip_stream);       /* NULL = the default stream */
 int oisat_stream_create(oisat_ctx* h);                      /* give this handle its own non-blocking stream: several
                                                                handles on one device then run concurrently (tiles) */
+int oisat_stream_create_masked(oisat_ctx* h, int reserve_per_xcd); /* like oisat_stream_create, but the stream's kernels keep
+                                                               off `reserve_per_xcd` CUs of every XCD (hipExtStreamCreateWithCUMask):
+                                                               used for the bulk group of a BatchedFactor so that the dependent
+                                                               chain of the critical group finds CUs free of GEMM waves.  Such a
+                                                               stream synchronises with the NULL stream (HIP: it is a blocking one) */
 int oisat_bind_thread(oisat_ctx* h);                        /* hipSetDevice(handle's device) for the CALLING host thread:
                                                                HIP's current device is per thread, so a worker thread that
                                                                drives a handle calls this once before anything else.  One

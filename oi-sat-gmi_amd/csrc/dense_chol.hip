@@ -1423,6 +1423,13 @@ int launch_gemm_batched(oisat_ctx* h, const char* name, const ChBatch& bt, Batch
     }
     if (cnt == 0) return OISAT_OK;
     static const int small_max = getenv("OISAT_SMALL_TILES") ? atoi(getenv("OISAT_SMALL_TILES")) : 700;
+    // OISAT_PROF_DETAIL=1 (profiling aid): one profile record per launch shape -- "name K tiles members" -- instead of per name
+    static const bool detail = getenv("OISAT_PROF_DETAIL") && atoi(getenv("OISAT_PROF_DETAIL")) != 0;
+    char dname[64];
+    if (detail && h->prof) {
+        snprintf(dname, sizeof(dname), "%s K%d t%lld n%d", name, K, (long long)sum, cnt);
+        name = dname;
+    }
     const BatchMat& big = bt.table[0];
     if (ba.kind == 1) {                                     // in-place TRSM: whole rows per workgroup
         const int64_t rows = big.mpb - ba.b0 - 1;

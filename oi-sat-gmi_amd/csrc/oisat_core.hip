@@ -88,6 +88,21 @@ extern "C" int oisat_stream_create(oisat_ctx* h) {
     return OISAT_OK;
 }
 
+extern "C" int oisat_stream_create_masked(oisat_ctx* h, int reserve_per_xcd) {
+    ARG_CHECK(h != nullptr && reserve_per_xcd >= 0 && h->own_stream == nullptr);
+    const int ncu = h->cu_count > 0 ? h->cu_count : 256;
+    ARG_CHECK(8 * reserve_per_xcd < ncu);
+    if (reserve_per_xcd == 0) return oisat_stream_create(h);
+    // bit i of a queue's CU mask is a CU of XCD (i mod 8) (probed with HW_REG_XCC_ID): the top
+    // 8 * reserve bits take `reserve` CUs off every XCD
+    std::vector<uint32_t> mask((ncu + 31) / 32, 0xffffffffu);
+    for (int b = ncu - 8 * reserve_per_xcd; b < (int)mask.size() * 32; ++b) mask[b / 32] &= ~(1u << (b % 32));
+    HIP_TRY(hipExtStreamCreateWithCUMask(&h->own_stream, (uint32_t)mask.size(), mask.data()));
+    h->stream = h->own_stream;
+    h->cu_count = ncu - 8 * reserve_per_xcd;            // grids sized per CU (persistent GEMMs, two-tile sweeps) follow the mask
+    return OISAT_OK;
+}
+
 extern "C" int oisat_bind_thread(oisat_ctx* h) {
     ARG_CHECK(h != nullptr);
     HIP_TRY(hipSetDevice(h->device));       // the current device is per host thread in HIP

@@ -33,6 +33,7 @@ SIGNATURES = {
     "oisat_bind_thread": (C.c_int, [_c_ctx]),
     "oisat_wait_for": (C.c_int, [_c_ctx, _c_ctx]),
     "oisat_query": (C.c_int, [_c_ctx, C.POINTER(C.c_int)]),
+    "oisat_stream_create_masked": (C.c_int, [_c_ctx, C.c_int]),
     "oisat_set_share": (C.c_int, [_c_ctx, C.c_int, C.c_int]),
     "oisat_set_refine_tol": (C.c_int, [_c_ctx, C.c_double]),
     "oisat_sync": (C.c_int, [_c_ctx]),
@@ -297,6 +298,11 @@ class Context:
     def own_stream(self):
         """Give this handle a stream of its own (used for concurrent tiles)."""
         self.check(self.lib.oisat_stream_create(self.h))
+        return self
+
+    def own_stream_masked(self, reserve_per_xcd: int):
+        """A stream of its own whose kernels keep off ``reserve_per_xcd`` CUs of every XCD."""
+        self.check(self.lib.oisat_stream_create_masked(self.h, int(reserve_per_xcd)))
         return self
 
     def bind_thread(self):

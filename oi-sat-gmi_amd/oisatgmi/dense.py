@@ -316,7 +316,12 @@ class BatchedFactor:
         # "sequential" -- the groups one after the other (each one's dependent chain then runs at its isolated speed and
         # its solves go underneath the next group's factorization).
         self.schedule = os.environ.get("OISAT_BATCH_SCHEDULE", "overlap")
-        self.ctxs = [_hip.Context(device).own_stream() for _ in self.groups]
+        # OISAT_BATCH_RESERVE_CUS=r: the groups other than the one with the longest chain run on streams that keep off r CUs
+        # of every XCD, which the critical group's chain kernels then find free of GEMM waves
+        reserve = int(os.environ.get("OISAT_BATCH_RESERVE_CUS", "0")) if len(groups) > 1 else 0
+        major0 = max(range(len(self.groups)), key=lambda gi: self.groups[gi][0].mp) if self.groups else 0
+        self.ctxs = [(_hip.Context(device).own_stream() if gi == major0 or reserve == 0
+                      else _hip.Context(device).own_stream_masked(reserve)) for gi in range(len(self.groups))]
         # sharing (oisat_set_share): the group with the longest chain is the critical path of the whole batch -- its waves
         # get priority on the SIMDs they share with the other groups' GEMMs, and the other groups' persistent GEMM launches
         # leave one workgroup slot per CU free (OISAT_BATCH_MAJOR_PRIO 0..3, OISAT_BATCH_MINOR_WG 1 | 2)

@@ -27,3 +27,10 @@ for a, b, n, gx, gy, wx in seg:
 print("span %.1f ms, %d kernels" % ((max(e[1] for e in seg) - t0) / 1e6, len(seg)))
 for k, (a, b, busy, cnt) in sorted(agg.items(), key=lambda kv: kv[1][0]):
     print("%-30s first %8.2f  last end %8.2f  busy %8.2f ms  x%-4d avg %7.1f us" % (k, (a - t0) / 1e6, (b - t0) / 1e6, busy / 1e6, cnt, busy / cnt / 1e3))
+if len(sys.argv) > 3 and float(sys.argv[3]) > 0:                    # the last kernels of the pass in time order: what runs after the factorizations are done
+    tail_ms = float(sys.argv[3])
+    tend = max(e[1] for e in seg)
+    print("---- kernels ending in the last %.1f ms" % tail_ms)
+    for a, b, n, gx, gy, wx in sorted(seg, key=lambda e: e[0]):
+        if (tend - b) / 1e6 <= tail_ms:
+            print("%9.3f ms  %8.1f us  %-22s grid %6d x %d" % ((a - t0) / 1e6, (b - a) / 1e3, short(n), gx // max(wx, 1), gy))

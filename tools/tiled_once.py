@@ -6,6 +6,8 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import numpy as np
 from oisatgmi import _hip, synthetic as syn, dense
 ctx = _hip.context()
+if os.environ.get('OWN_STREAM', '1') == '1':
+    ctx.own_stream()          # lane 0 off the NULL stream (a CU-masked stream synchronises with it)
 refine = int(os.environ.get("REFINE", "2"))
 p = syn.point_obs_case(720, 1440, 100000, 4000, swaths=True)
 ta = dense.TiledAnalysis(p.lat, p.lon, tile_deg=30.0, halo_km=900.0, dtype=np.float32, ctx=ctx, streams=int(os.environ.get("LANES", "12")))

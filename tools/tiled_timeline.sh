@@ -7,6 +7,6 @@ cd /tmp && export TMPDIR=/tmp
 d=$R/gpurun_out/tl_$$
 rocprofv3 --kernel-trace -d $d -o t --output-format csv -- python3 $R/tools/tiled_once.py > $out.run 2>&1
 f=$(find $d -name "*kernel_trace.csv" | head -1)
-python3 $R/tools/phases.py $f > $out
+python3 $R/tools/phases.py $f 2 ${TAIL_MS:-0} > $out
 rm -rf $d
 cat $out.run | tail -4; cat $out
