@@ -76,6 +76,51 @@ __global__ __launch_bounds__(256) void boxfilter_pick_kernel(const T* __restrict
     }
 }
 
+// Row-wise form (kx <= 64): a wave takes 64 / kx consecutive targets, lane = (target slot, window column b).  For the
+// regular grids of _upscaler consecutive model cells pick consecutive windows, so for each of the ky window rows the
+// wave's ONE load instruction reads up to 64 consecutive floats of a fine-grid row -- whole 128-byte lines, each fetched
+// once -- where the lane-strided form above reads ten 40-byte pieces per instruction (1.8x the algorithmic bytes left L2
+// for the fabric: the pieces of a line went to different XCDs).  Blocks are renumbered so that every XCD (private L2)
+// owns one contiguous range of targets.  Per window: column sums over the rows (row order), then the columns left to
+// right on the slot's first lane -- a fixed order.
+template <typename T>
+__global__ __launch_bounds__(256) void boxfilter_pick_rows_kernel(const T* __restrict__ Z, int64_t Ny, int64_t Nx, int nfields,
+                                                                   int ky, int kx, T w, const int32_t* __restrict__ idx, int64_t Tn,
+                                                                   T* __restrict__ out, int tpw, int64_t waves_per_field) {
+    const unsigned nb = gridDim.x;                                     // a multiple of 8 (host)
+    const unsigned blk = (blockIdx.x & 7u) * (nb >> 3) + (blockIdx.x >> 3);
+    const int lane = threadIdx.x & 63;
+    const int slot = lane / kx, b = lane - slot * kx;
+    const int64_t total = waves_per_field * nfields;
+    for (int64_t wq = (int64_t)blk * 4 + (threadIdx.x >> 6); wq < total; wq += (int64_t)nb * 4) {     // wave-uniform
+        const int64_t f = wq / waves_per_field, tw = wq - f * waves_per_field;
+        const int64_t t = tw * tpw + slot;
+        const bool live = slot < tpw && t < Tn;
+        const int32_t node = live ? idx[t] : -1;
+        T acc = T(0);
+        if (node >= 0) {
+            const int64_t i = node / Nx, j = node % Nx;
+            const int64_t col = reflect(j - kx / 2 + b, Nx);
+            const T* Zf = Z + f * Ny * Nx;
+            // eight window rows in flight at a time (independent loads), added in row order
+            for (int a0 = 0; a0 < ky; a0 += 8) {
+                T v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = (a0 + q < ky) ? Zf[reflect(i - ky / 2 + a0 + q, Ny) * Nx + col] : T(0);
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (a0 + q < ky) acc += v[q] * w;
+            }
+        }
+        T tot = acc;
+        for (int bb = 1; bb < kx; ++bb) {
+            const T o = __shfl(acc, (lane + bb) & 63, kWave);
+            if (b == 0) tot += o;
+        }
+        if (live && b == 0) out[f * Tn + t] = node >= 0 ? tot : nan_of<T>();
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void gather_mask_kernel(const T* __restrict__ values, int64_t P, int nfields,
                                                            const int32_t* __restrict__ idx, int64_t Tn, T* __restrict__ out) {
@@ -133,38 +178,97 @@ __global__ __launch_bounds__(256) void nn_count_kernel(const double* __restrict_
     }
 }
 
-// single-block exclusive scan over ncell counters (ncell is at most a few hundred thousand)
-__global__ __launch_bounds__(1024) void nn_scan_kernel(const unsigned* __restrict__ counts, int64_t ncell,
-                                                        unsigned* __restrict__ start, unsigned* __restrict__ cursor) {
-    __shared__ unsigned part[1024];
-    const int t = threadIdx.x;
-    const int64_t chunk = (ncell + 1023) / 1024;
-    const int64_t b = t * chunk, e = (b + chunk < ncell) ? b + chunk : ncell;
-    unsigned s = 0;
-    for (int64_t i = b; i < e; ++i) s += counts[i];
-    part[t] = s;
+// Exclusive scan of the cell counters.  One tile = 4096 counters: 1024 threads x 4 consecutive values, wave scans by
+// shuffle, the 16 wave totals scanned by wave 0.  (Round 2's version was one block that gave every thread one long chunk
+// and walked it with dependent loads: 31 us for 17,000 cells.)
+__device__ __forceinline__ unsigned tile_scan4(const unsigned v[4], unsigned ex[4], unsigned* wsum /*[17] shared*/) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const unsigned tsum = v[0] + v[1] + v[2] + v[3];
+    unsigned inc = tsum;                                          // inclusive scan over the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned up = __shfl_up(inc, o, kWave);
+        if (lane >= o) inc += up;
+    }
+    __syncthreads();                                              // wsum of the previous tile has been consumed
+    if (lane == 63) wsum[wv] = inc;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        unsigned v = t >= off ? part[t - off] : 0u;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
+    if (wv == 0) {
+        unsigned x = lane < 16 ? wsum[lane] : 0u, xi = x;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            const unsigned up = __shfl_up(xi, o, kWave);
+            if (lane >= o) xi += up;
+        }
+        if (lane < 16) wsum[lane] = xi - x;                       // exclusive wave offsets
+        if (lane == 15) wsum[16] = xi;                            // tile total
     }
-    unsigned run = t == 0 ? 0u : part[t - 1];
-    for (int64_t i = b; i < e; ++i) {
-        start[i] = run;
-        cursor[i] = run;
-        run += counts[i];
+    __syncthreads();
+    unsigned run = wsum[wv] + inc - tsum;
+    ex[0] = run; run += v[0];
+    ex[1] = run; run += v[1];
+    ex[2] = run; run += v[2];
+    ex[3] = run;
+    return wsum[16];
+}
+
+// Single-pass scan with decoupled look-back: block = one tile of 4096 counters (taken by ticket, so every predecessor has
+// started), publishes its tile total, sums the totals / prefixes of the tiles before it, publishes its inclusive prefix.
+// status[t]: bits 62-63 = 1 (tile total) | 2 (inclusive prefix), low 32 bits the value; status and ticket arrive zeroed.
+__global__ __launch_bounds__(1024) void nn_scan_lookback_kernel(const unsigned* __restrict__ counts, int64_t n, unsigned* __restrict__ start,
+                                                                 unsigned* __restrict__ cursor, unsigned long long* __restrict__ status,
+                                                                 unsigned* __restrict__ ticket) {
+    __shared__ unsigned wsum[17];
+    __shared__ unsigned s_tile, s_prev;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const int64_t tile = s_tile, first = tile * 4096, last = first + 4096 < n ? first + 4096 : n;
+    const int64_t i = first + (int64_t)tid * 4;
+    unsigned v[4], ex[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = (i + q < last) ? counts[i + q] : 0u;
+    const unsigned tot = tile_scan4(v, ex, wsum);
+    if (tid == 0) {
+        unsigned prev = 0;
+        if (tile > 0) {
+            __hip_atomic_store(&status[tile], (1ull << 62) | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int64_t j = tile - 1; j >= 0; --j) {
+                unsigned long long st;
+                unsigned spins = 0;
+                while (((st = __hip_atomic_load(&status[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 62) == 0ull) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1u << 24)) break;                    // bounded: a predecessor always publishes (it holds a lower ticket)
+                }
+                prev += (unsigned)(st & 0xffffffffull);
+                if ((st >> 62) == 2ull) break;
+            }
+        }
+        __hip_atomic_store(&status[tile], (2ull << 62) | (unsigned long long)(prev + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_prev = prev;
+        if (last == n) start[n] = prev + tot;
     }
-    if (t == 1023) start[ncell] = part[1023];
+    __syncthreads();
+    const unsigned carry = s_prev;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (i + q < last) {
+            start[i + q] = carry + ex[q];
+            cursor[i + q] = carry + ex[q];
+        }
 }
 
 __global__ __launch_bounds__(256) void nn_scatter_kernel(const int32_t* __restrict__ pcell, int64_t P, unsigned* __restrict__ cursor,
-                                                          int32_t* __restrict__ sorted) {
+                                                          int32_t* __restrict__ sorted, const double* __restrict__ px,
+                                                          const double* __restrict__ py, double2* __restrict__ sxy) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += stride) {
         const int c = pcell[i];
-        if (c >= 0) sorted[atomicAdd(&cursor[c], 1u)] = (int32_t)i;
+        if (c >= 0) {
+            const unsigned pos = atomicAdd(&cursor[c], 1u);
+            sorted[pos] = (int32_t)i;
+            sxy[pos] = make_double2(px[i], py[i]);          // the query walks a cell's points as one contiguous run
+        }
     }
 }
 
@@ -173,8 +277,8 @@ __global__ __launch_bounds__(256) void nn_scatter_kernel(const int32_t* __restri
 __global__ __launch_bounds__(256) void nn_query_kernel(const double* __restrict__ px, const double* __restrict__ py,
                                                         const double* __restrict__ tx, const double* __restrict__ ty, int64_t Tn,
                                                         HashGrid g, const unsigned* __restrict__ start,
-                                                        const int32_t* __restrict__ sorted, double max_dist,
-                                                        int32_t* __restrict__ idx_out, double* __restrict__ dist_out,
+                                                        const int32_t* __restrict__ sorted, const double2* __restrict__ sxy,
+                                                        double max_dist, int32_t* __restrict__ idx_out, double* __restrict__ dist_out,
                                                         int32_t* __restrict__ tie_list, unsigned* __restrict__ tie_count) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < Tn; t += stride) {
@@ -190,11 +294,15 @@ __global__ __launch_bounds__(256) void nn_query_kernel(const double* __restrict_
                     if (xx < 0 || xx >= g.nbx) continue;
                     const int c = yy * g.nbx + xx;
                     for (unsigned s = start[c]; s < start[c + 1]; ++s) {
-                        const int32_t i = sorted[s];
-                        const double dx = px[i] - x, dy = py[i] - y;
+                        const double2 p = sxy[s];
+                        const double dx = p.x - x, dy = p.y - y;
                         const double d2 = dx * dx + dy * dy;
-                        if (d2 < best || (d2 == best && i < bi)) { second = best; best = d2; bi = i; }
-                        else if (d2 < second) second = d2;
+                        if (d2 < best) { second = best; best = d2; bi = sorted[s]; }
+                        else if (d2 == best) {                  // exact tie: lowest point index (the order inside a cell is arbitrary)
+                            const int32_t i = sorted[s];
+                            second = best;
+                            if (i < bi) bi = i;
+                        } else if (d2 < second) second = d2;
                     }
                 }
             }
@@ -562,6 +670,17 @@ static int pick_impl(oisat_ctx* h, const void* Z, int64_t Ny, int64_t Nx, int nf
                      const int32_t* idx, int64_t Tn, void* out) {
     const int win = ky * kx;
     const int64_t groups = Tn * nfields;
+    static const bool rows_form = !getenv("OISAT_BOXFILTER_ROWS") || atoi(getenv("OISAT_BOXFILTER_ROWS")) != 0;
+    if (rows_form && kx <= 64 && win >= 3) {
+        const int tpw = 64 / kx;
+        const int64_t wpf = cdiv(Tn, tpw);
+        int64_t blocks = cdiv(wpf * nfields, 4);
+        if (blocks > 8192) blocks = 8192;
+        blocks = cdiv(blocks, 8) * 8;
+        OISAT_LAUNCH(h, "boxfilter_pick", (boxfilter_pick_rows_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, (const T*)Z, Ny, Nx,
+                     nfields, ky, kx, (T)w, idx, Tn, (T*)out, tpw, wpf);
+        return OISAT_OK;
+    }
     if (win >= 48) {
         const int grid = stream_grid(groups * 64, 256);
         OISAT_LAUNCH(h, "boxfilter_pick", (boxfilter_pick_kernel<T, 64>), dim3(grid), dim3(256), 0, (const T*)Z, Ny, Nx, nfields,
@@ -666,7 +785,7 @@ __global__ __launch_bounds__(256) void minmax_kernel(const double* __restrict__ 
 // Hash the points into uniform cells of edge `cell` (coarsened if that would need too many cells).
 // On return start[c]..start[c+1] index `sorted` (point ids of cell c); both live in workspace slot 2.
 static int build_hash(oisat_ctx* h, const double* plon, const double* plat, int64_t P, double cell, HashGrid* g_out,
-                      const unsigned** start_out, const int32_t** sorted_out) {
+                      const unsigned** start_out, const int32_t** sorted_out, const double2** sxy_out = nullptr) {
     // 1. bounding box of the points
     const int mm_blocks = 64;
     double* mm_dev = (double*)oisat_ws(h, 1, sizeof(double) * 4 * mm_blocks);
@@ -692,28 +811,37 @@ static int build_hash(oisat_ctx* h, const double* plon, const double* plat, int6
     g.nbx = (int)floor(spanx / cell) + 1;
     g.nby = (int)floor(spany / cell) + 1;
     const int64_t ncell = (int64_t)g.nbx * g.nby;
-    // workspace slot 2: counts | start (ncell+1) | cursor | pcell (P) | sorted (P)
+    // workspace slot 2: counts | scan status (one word per tile of 4096) + ticket | start (ncell+1) | cursor | pcell (P) | sorted (P)
+    const int64_t ntile = cdiv(ncell, 4096);
     const size_t o_counts = 0;
-    const size_t o_start = o_counts + sizeof(unsigned) * (ncell + 4);
+    const size_t o_status = (o_counts + sizeof(unsigned) * (ncell + 4) + 7) / 8 * 8;
+    const size_t o_ticket = o_status + sizeof(unsigned long long) * (ntile + 1);
+    const size_t o_start = o_ticket + 16;
     const size_t o_cursor = o_start + sizeof(unsigned) * (ncell + 4);
     const size_t o_pcell = o_cursor + sizeof(unsigned) * (ncell + 4);
     const size_t o_sorted = o_pcell + sizeof(int32_t) * (P + 4);
-    const size_t total = o_sorted + sizeof(int32_t) * (P + 4);
+    const size_t o_sxy = (o_sorted + sizeof(int32_t) * (P + 4) + 15) / 16 * 16;          // coordinates in cell order
+    const size_t total = o_sxy + sizeof(double2) * (P + 4);
     char* ws = (char*)oisat_ws(h, 2, total);
     if (!ws) return OISAT_ENOMEM;
     unsigned* counts = (unsigned*)(ws + o_counts);
+    unsigned long long* status = (unsigned long long*)(ws + o_status);
+    unsigned* ticket = (unsigned*)(ws + o_ticket);
     unsigned* start = (unsigned*)(ws + o_start);
     unsigned* cursor = (unsigned*)(ws + o_cursor);
     int32_t* pcell = (int32_t*)(ws + o_pcell);
     int32_t* sorted = (int32_t*)(ws + o_sorted);
-    HIP_TRY(hipMemsetAsync(counts, 0, sizeof(unsigned) * (ncell + 4), h->stream));
+    double2* sxy = (double2*)(ws + o_sxy);
+    HIP_TRY(hipMemsetAsync(counts, 0, o_start, h->stream));             // counters, scan status words and ticket in one fill
     OISAT_LAUNCH(h, "nn_count", nn_count_kernel, dim3(stream_grid(P, 256)), dim3(256), 0, plon, plat, P, g, counts, pcell);
-    OISAT_LAUNCH(h, "nn_scan", nn_scan_kernel, dim3(1), dim3(1024), 0, (const unsigned*)counts, ncell, start, cursor);
+    OISAT_LAUNCH(h, "nn_scan", nn_scan_lookback_kernel, dim3((unsigned)ntile), dim3(1024), 0, (const unsigned*)counts, ncell, start,
+                 cursor, status, ticket);
     OISAT_LAUNCH(h, "nn_scatter", nn_scatter_kernel, dim3(stream_grid(P, 256)), dim3(256), 0, (const int32_t*)pcell, P, cursor,
-                 sorted);
+                 sorted, plon, plat, sxy);
     *g_out = g;
     *start_out = start;
     *sorted_out = sorted;
+    if (sxy_out) *sxy_out = sxy;
     return OISAT_OK;
 }
 
@@ -725,7 +853,8 @@ static int nn_query_impl(oisat_ctx* h, const double* plon, const double* plat, i
     HashGrid g;
     const unsigned* start;
     const int32_t* sorted;
-    const int rc = build_hash(h, plon, plat, P, max_dist, &g, &start, &sorted);
+    const double2* sxy;
+    const int rc = build_hash(h, plon, plat, P, max_dist, &g, &start, &sorted, &sxy);
     if (rc != OISAT_OK) return rc;
     unsigned* count = nullptr;
     unsigned* count_host = nullptr;
@@ -735,8 +864,10 @@ static int nn_query_impl(oisat_ctx* h, const double* plon, const double* plat, i
         if (!count || !count_host) return OISAT_ENOMEM;
         HIP_TRY(hipMemsetAsync(count, 0, 64, h->stream));
     }
-    OISAT_LAUNCH(h, "nn_query", nn_query_kernel, dim3(stream_grid(Tn, 256)), dim3(256), 0, plon, plat, tlon, tlat, Tn, g, start,
-                 sorted, max_dist, idx_out, dist_out, tie_list, count);
+    // latency-bound (dependent loads through the hash): one target per thread up to 16,384 blocks
+    const int64_t qgrid = cdiv(Tn, 256) < 16384 ? cdiv(Tn, 256) : 16384;
+    OISAT_LAUNCH(h, "nn_query", nn_query_kernel, dim3((unsigned)qgrid), dim3(256), 0, plon, plat, tlon, tlat, Tn, g, start,
+                 sorted, sxy, max_dist, idx_out, dist_out, tie_list, count);
     if (tie_list) {
         HIP_TRY(hipMemcpyAsync(count_host, count, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
