@@ -24,6 +24,7 @@ stream for the roofline object, the element-wise (reference-parity) OI on the sa
 bounded CPU run of the float64 oracle for cpu_baseline.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -127,16 +128,17 @@ def roofline_leg(ctx, plan, L, refine, psteps):
     chol_flops = m ** 3 / 3.0
     achieved = chol_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     traffic, traffic_src = None, None
-    tfile = os.path.join(ROOT, "profiles", "r01_f_c3_hbm_traffic_pmc.json")
-    if m > 90000 and os.path.exists(tfile):       # PMC pass of this same workload (rocprofv3 --pmc, offline)
-        tj = json.load(open(tfile))
+    tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c3_hbm_traffic_pmc.json")))
+    if m > 90000 and tfiles:                      # newest PMC pass of this same workload (tools/pmc_traffic.sh, offline)
+        tj = json.load(open(tfiles[-1]))
         traffic = tj["hbm_bytes_per_factorization_corrected"] / tj["launches_per_factorization"]
-        traffic_src = ("profiles/r01_f_c3_hbm_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
-                       "FETCH x2 per the gfx950 note; bytes per gemm_nt launch, mean over the launches of one factorization)")
+        traffic_src = (f"profiles/{os.path.basename(tfiles[-1])} at commit {tj.get('commit')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                       "separate passes, FETCH x2 per the gfx950 note; bytes per gemm_nt* launch, mean over the launches of one "
+                       "factorization)")
     roof = {
         "bound": "mfma",
-        "kernel": "gemm_nt_kernel + gemm_nt_small_kernel (the syrk_gemm + trsm_gemm launches of one Cholesky factorization; "
-                  "the 64x64-tile kernel takes the launches of <= 700 tiles, 0.9 % of the GEMM time at this size)",
+        "kernel": "gemm_nt_big_kernel (K >= 2048: 93 % of the GEMM time at the headline size) + gemm_nt_kernel (persistent, K < 2048) + "
+                  "gemm_nt_small_kernel + gemm_nt_rows64_kernel: the syrk_gemm + trsm_gemm launches of one Cholesky factorization",
         "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
         "traffic": traffic, "traffic_source": traffic_src,
         "algorithmic_flops_per_step": chol_flops, "kernel_ms_per_step": gemm_ms, "launches_per_step": gemm_launches,
