@@ -184,20 +184,30 @@ def tier_a_leg(ctx, ny, nx, nobs, sync):
                                           "8 B/cell read once = %.1f GB/s" % (8.0 * n / (curve_ms * 1e-3) / 1e9)}}
 
 
-TIER_A_PMC = os.path.join(ROOT, "profiles", "r02_a_tier_a_pmc_traffic.json")
+def _tier_a_pmc():
+    """newest PMC pass of the Tier-A leg (tools/pmc_traffic.sh ... -- python3 bench.py --tier-a-only): kernel -> bytes per dispatch"""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_tier_a_hbm_traffic_pmc.json")))
+    if files:
+        tj = json.load(open(files[-1]))
+        return ({k: v["bytes_per_dispatch"] for k, v in tj["kernels"].items()},
+                f"profiles/{os.path.basename(files[-1])} at commit {tj.get('commit')}")
+    old = os.path.join(ROOT, "profiles", "r02_a_tier_a_pmc_traffic.json")
+    if os.path.exists(old):
+        return {k: v["total"] for k, v in json.load(open(old))["bytes_per_dispatch"].items()}, "profiles/r02_a_tier_a_pmc_traffic.json"
+    return {}, None
 
 
 def _hbm(bytes_, ms, pmc_kernel=None):
     """HBM roofline entry of one kernel launch; `traffic` = bytes the PMC passes of this same leg counted for that kernel
-    (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, offline: profiles/r02_a_tier_a_pmc_traffic.json), per launch."""
+    (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2, offline), per launch."""
     gbs = bytes_ / (ms * 1e-3) / 1e9
     out = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
            "algorithmic_bytes": int(bytes_), "kernel_ms": ms, "traffic": None}
-    if pmc_kernel and os.path.exists(TIER_A_PMC):
-        rec = json.load(open(TIER_A_PMC))["bytes_per_dispatch"].get(pmc_kernel)
-        if rec:
-            out["traffic"] = rec["total"]
-            out["traffic_source"] = "profiles/r02_a_tier_a_pmc_traffic.json: " + pmc_kernel
+    if pmc_kernel:
+        table, src = _tier_a_pmc()
+        if pmc_kernel in table:
+            out["traffic"] = table[pmc_kernel]
+            out["traffic_source"] = f"{src}: {pmc_kernel}"
     return out
 
 
@@ -256,7 +266,7 @@ def tier_a_kernels_leg(ctx, sync):
         fine = ctx.upload(rng.uniform(0.0, 1.0, size=(nf, n)), dtype=dt)
         t = _prof_mean(ctx, lambda: plan.run(fine, nf, dt, False), 10)
         out[f"boxfilter_pick_{tag}"] = _hbm(nf * plan.T * (plan.kx * plan.ky + 1) * item, t["boxfilter_pick"],
-                                            f"boxfilter_pick_kernel<{cname}, 64>")
+                                            f"boxfilter_pick_rows_kernel<{cname}>")
         out[f"boxfilter_pick_{tag}"]["window"] = [plan.ky, plan.kx]
         out[f"boxfilter_pick_{tag}"]["model_cells"] = plan.T
         fine.free()
