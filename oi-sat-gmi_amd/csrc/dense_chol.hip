@@ -713,6 +713,258 @@ __global__ __launch_bounds__(256) void gemm_nt_rows64_kernel(float* C, int64_t l
     }
 }
 
+// ---- leaf PAIRS: two block columns (b, b+1) per leaf of the recursion ---------------------------------------------------
+// With one block per leaf the rows below a pair of diagonal blocks are swept three times at K = 128 -- TRSM with T_b, the
+// rank-128 update of column b+1, TRSM with T_b+1 -- each pass reading and writing a 64-KB tile per 4.2 MFLOP (16 flop/B:
+// HBM-bound; in a month of 48 tiles these launches are 40 % of the factorization time for 10 % of its flops).  The pair
+// form makes ONE pass:  P1 = X1 T_b^T;  X2 -= P1 L21^T;  P2 = X2 T_b+1^T  per 64 rows, with P1 and X2 handed from one
+// product to the next through an LDS image (pair_panel_kernel), after a one-workgroup step has produced
+// L21 = S[b+1,b] T_b^T and S[b+1,b+1] -= L21 L21^T between the two diagonal factorizations (pair_mid_kernel).
+// Same products, same k order and the same single rounding of C - sum as the three launches they replace.
+typedef float v4f __attribute__((ext_vector_type(4)));
+constexpr int LDP = NB + 4;                // row stride of a full-K LDS operand image (floats)
+
+// whole B operand [128 x 128] of one product into registers: 16 float4 per thread (chunk kt = rb[4 kt .. 4 kt + 3]), all
+// loads in flight at once -- these kernels are latency-bound when few workgroups run (a polar cap, a single system)
+__device__ __forceinline__ void b_load_all(v4f (&rb)[16], const float* __restrict__ g, int64_t ldg, int t) {
+    const float* p = g + (int64_t)(t >> 3) * ldg + (t & 7) * 4;
+#define OISAT_BL(kt, q) rb[4 * (kt) + (q)] = *reinterpret_cast<const v4f*>(p + (int64_t)(32 * (q)) * ldg + (kt) * BK);
+    OISAT_BL(0, 0) OISAT_BL(0, 1) OISAT_BL(0, 2) OISAT_BL(0, 3) OISAT_BL(1, 0) OISAT_BL(1, 1) OISAT_BL(1, 2) OISAT_BL(1, 3)
+    OISAT_BL(2, 0) OISAT_BL(2, 1) OISAT_BL(2, 2) OISAT_BL(2, 3) OISAT_BL(3, 0) OISAT_BL(3, 1) OISAT_BL(3, 2) OISAT_BL(3, 3)
+#undef OISAT_BL
+}
+
+// acc0 | acc1 (a wave's 32 x 64 piece: rows wr*32.., columns wc*64.. and +32) += A[64 x 128] B[128 x 128]^T, A from a full-K
+// LDS image (stride LDP), B from registers (b_load_all) through the one-chunk LDS image `ldsB`.  next != nullptr: as soon
+// as chunk kt has gone to LDS its registers are refilled with chunk kt of the NEXT product's B operand, so that product
+// finds its operand in registers -- one register set, and only the first product of a kernel waits for memory.
+template <int KT, bool NEXT>
+__device__ __forceinline__ void rows64_chunk(f32x16& acc0, f32x16& acc1, const float* __restrict__ imgA, v4f (&rb)[16],
+                                             float* __restrict__ ldsB, int t, const float* __restrict__ next, int64_t ldnext) {
+    const int lane = t & 63, wid = t >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    const int frow = lane & 31, fh = lane >> 5;
+    const int aoff = (wr * 32 + frow) * LDP + 4 * fh, boff = (wc * 64 + frow) * LDSW + 4 * fh;
+    const int srow = t >> 3, sk = (t & 7) * 4;
+    __syncthreads();                                                    // the previous chunk (or the image's writers) are done
+    *reinterpret_cast<v4f*>(&ldsB[(srow + 0) * LDSW + sk]) = rb[4 * KT + 0];
+    *reinterpret_cast<v4f*>(&ldsB[(srow + 32) * LDSW + sk]) = rb[4 * KT + 1];
+    *reinterpret_cast<v4f*>(&ldsB[(srow + 64) * LDSW + sk]) = rb[4 * KT + 2];
+    *reinterpret_cast<v4f*>(&ldsB[(srow + 96) * LDSW + sk]) = rb[4 * KT + 3];
+    if (NEXT) {
+        const float* g = next + (int64_t)srow * ldnext + KT * BK + sk;
+        rb[4 * KT + 0] = *reinterpret_cast<const v4f*>(g);
+        rb[4 * KT + 1] = *reinterpret_cast<const v4f*>(g + 32 * ldnext);
+        rb[4 * KT + 2] = *reinterpret_cast<const v4f*>(g + 64 * ldnext);
+        rb[4 * KT + 3] = *reinterpret_cast<const v4f*>(g + 96 * ldnext);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        const float4 a = *reinterpret_cast<const float4*>(&imgA[aoff + KT * BK + 8 * s4]);
+        const float4 b0 = *reinterpret_cast<const float4*>(&ldsB[boff + 8 * s4]);
+        const float4 b1 = *reinterpret_cast<const float4*>(&ldsB[boff + 32 * LDSW + 8 * s4]);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
+    }
+}
+
+template <bool NEXT>
+__device__ __forceinline__ void rows64_product(f32x16& acc0, f32x16& acc1, const float* __restrict__ imgA, v4f (&rb)[16],
+                                               float* __restrict__ ldsB, int t, const float* __restrict__ next, int64_t ldnext) {
+    rows64_chunk<0, NEXT>(acc0, acc1, imgA, rb, ldsB, t, next, ldnext);
+    rows64_chunk<1, NEXT>(acc0, acc1, imgA, rb, ldsB, t, next, ldnext);
+    rows64_chunk<2, NEXT>(acc0, acc1, imgA, rb, ldsB, t, next, ldnext);
+    rows64_chunk<3, NEXT>(acc0, acc1, imgA, rb, ldsB, t, next, ldnext);
+}
+
+// element (e, half) of a wave's accumulator pair -> (row, column) inside the 64 x 128 piece of the workgroup
+#define OISAT_PIECE_ROW(e) (wr * 32 + ((e) & 3) + 8 * ((e) >> 2) + 4 * fh)
+#define OISAT_PIECE_COL(half) (wc * 64 + 32 * (half) + frow)
+
+// rows of 64 below a leaf pair (b, b+1): one pass over S[rows, b*128 : (b+2)*128].  Every global load is issued as early
+// as registers allow: X1 and T_b at once, L21 while the first product runs, T_b+1 and X2 while the second one does.
+template <bool BATCH>
+__global__ __launch_bounds__(256) void pair_panel_kernel(float* __restrict__ S, int64_t ld, int mpb, const float* __restrict__ tinv,
+                                                          int b, const BatchMat* __restrict__ mats, int prio) {
+    __shared__ __attribute__((aligned(16))) float img[SB * LDP];         // 33,792 B: X1 -> P1 -> X2'
+    __shared__ __attribute__((aligned(16))) float ldsB[NB * LDSW];       // 18,432 B
+    chain_prio();
+    group_prio(prio);
+    if (BATCH) {
+        const BatchMat* bm = mats + blockIdx.y;
+        S = bm->S;
+        ld = bm->ld;
+        mpb = bm->mpb;
+        tinv = bm->tinv;
+    }
+    if ((int)blockIdx.x >= (mpb - b - 2) * 2) return;                   // this matrix has fewer rows below the pair (or none)
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const int wr = wid >> 1, wc = wid & 1, frow = lane & 31, fh = lane >> 5;
+    float* X1 = S + ((int64_t)(b + 2) * NB + (int64_t)blockIdx.x * SB) * ld + (int64_t)b * NB;      // my 64 rows, column block b
+    float* X2 = X1 + NB;                                                                            // ... column block b+1
+    const float* Tb = tinv + (int64_t)b * NB * NB;
+    const float* Tb1 = Tb + NB * NB;
+    const float* L21 = S + (int64_t)(b + 1) * NB * ld + (int64_t)b * NB;
+    v4f rb[16];
+    {
+        v4f xr[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) xr[q] = *reinterpret_cast<const v4f*>(X1 + (int64_t)((t >> 5) + 8 * q) * ld + (t & 31) * 4);
+        b_load_all(rb, Tb, NB, t);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) *reinterpret_cast<v4f*>(&img[((t >> 5) + 8 * q) * LDP + (t & 31) * 4]) = xr[q];
+    }
+    f32x16 acc0 = {0}, acc1 = {0};
+    rows64_product<true>(acc0, acc1, img, rb, ldsB, t, L21, ld);              // P1 = X1 T_b^T            (rb <- L21 on the way)
+    __syncthreads();                                                    // every wave has read X1 from the image
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int r = OISAT_PIECE_ROW(e);
+        X1[(int64_t)r * ld + OISAT_PIECE_COL(0)] = acc0[e];
+        X1[(int64_t)r * ld + OISAT_PIECE_COL(1)] = acc1[e];
+        img[r * LDP + OISAT_PIECE_COL(0)] = acc0[e];
+        img[r * LDP + OISAT_PIECE_COL(1)] = acc1[e];
+    }
+    f32x16 x2a, x2b;                                                    // my elements of X2, in accumulator layout
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int r = OISAT_PIECE_ROW(e);
+        x2a[e] = X2[(int64_t)r * ld + OISAT_PIECE_COL(0)];
+        x2b[e] = X2[(int64_t)r * ld + OISAT_PIECE_COL(1)];
+    }
+    acc0 = f32x16{0};
+    acc1 = f32x16{0};
+    rows64_product<true>(acc0, acc1, img, rb, ldsB, t, Tb1, NB);              // Q = P1 L21^T             (rb <- T_b+1 on the way)
+    __syncthreads();                                                    // every wave has read P1 from the image
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {                                      // X2' = X2 - Q, rounded once, as the rank-128 update does
+        const int r = OISAT_PIECE_ROW(e);
+        img[r * LDP + OISAT_PIECE_COL(0)] = x2a[e] - acc0[e];
+        img[r * LDP + OISAT_PIECE_COL(1)] = x2b[e] - acc1[e];
+    }
+    acc0 = f32x16{0};
+    acc1 = f32x16{0};
+    rows64_product<false>(acc0, acc1, img, rb, ldsB, t, (const float*)nullptr, 0);      // P2 = X2' T_b+1^T
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int r = OISAT_PIECE_ROW(e);
+        X2[(int64_t)r * ld + OISAT_PIECE_COL(0)] = acc0[e];
+        X2[(int64_t)r * ld + OISAT_PIECE_COL(1)] = acc1[e];
+    }
+}
+
+// one 64-row half of pair_mid's second product: D_half -= L21_half L21^T (B = L21 from registers)
+__device__ __forceinline__ void pair_mid_update(float* __restrict__ Dh, int64_t ld, const float* __restrict__ imgA, v4f (&rb)[16],
+                                                float* __restrict__ ldsB, int t, bool keep_b) {
+    const int lane = t & 63, wid = t >> 6;
+    const int wr = wid >> 1, wc = wid & 1, frow = lane & 31, fh = lane >> 5;
+    f32x16 d0, d1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int r = OISAT_PIECE_ROW(e);
+        d0[e] = Dh[(int64_t)r * ld + OISAT_PIECE_COL(0)];
+        d1[e] = Dh[(int64_t)r * ld + OISAT_PIECE_COL(1)];
+    }
+    f32x16 a0 = {0}, a1 = {0};
+    (void)keep_b;
+    rows64_product<false>(a0, a1, imgA, rb, ldsB, t, (const float*)nullptr, 0);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int r = OISAT_PIECE_ROW(e);
+        Dh[(int64_t)r * ld + OISAT_PIECE_COL(0)] = d0[e] - a0[e];
+        Dh[(int64_t)r * ld + OISAT_PIECE_COL(1)] = d1[e] - a1[e];
+    }
+}
+
+// between the two diagonal factorizations of a pair: L21 = S[b+1,b] T_b^T (in place), S[b+1,b+1] -= L21 L21^T.  One
+// workgroup per matrix, on the dependent chain: X and T_b are requested at once, L21 is handed from the first product to
+// the second through LDS (as A image and, chunk by chunk, as B), 64 rows at a time.
+template <bool BATCH>
+__global__ __launch_bounds__(256) void pair_mid_kernel(float* __restrict__ S, int64_t ld, int mpb, const float* __restrict__ tinv, int b,
+                                                        const BatchMat* __restrict__ mats, int prio) {
+    __shared__ __attribute__((aligned(16))) float img0[SB * LDP], img1[SB * LDP];      // the two 64-row halves of X, then of L21
+    __shared__ __attribute__((aligned(16))) float ldsB[NB * LDSW];                     // 67,584 + 18,432 B
+    chain_prio();
+    group_prio(prio);
+    if (BATCH) {
+        const BatchMat* bm = mats + blockIdx.x;
+        S = bm->S;
+        ld = bm->ld;
+        mpb = bm->mpb;
+        tinv = bm->tinv;
+    }
+    if (b + 1 >= mpb) return;                                           // the pair's second block does not exist in this matrix
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const int wr = wid >> 1, wc = wid & 1, frow = lane & 31, fh = lane >> 5;
+    float* X = S + (int64_t)(b + 1) * NB * ld + (int64_t)b * NB;          // S[b+1, b]
+    float* D = X + NB;                                                    // S[b+1, b+1]
+    v4f rb[16];
+    {
+        v4f xr[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) xr[q] = *reinterpret_cast<const v4f*>(X + (int64_t)((t >> 5) + 8 * q) * ld + (t & 31) * 4);
+        b_load_all(rb, tinv + (int64_t)b * NB * NB, NB, t);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            *reinterpret_cast<v4f*>(&img0[((t >> 5) + 8 * q) * LDP + (t & 31) * 4]) = xr[q];
+            *reinterpret_cast<v4f*>(&img1[((t >> 5) + 8 * q) * LDP + (t & 31) * 4]) = xr[8 + q];
+        }
+    }
+    // L21 = X T_b^T: both halves need the same B, so its registers are refilled with T_b itself for the second half
+    f32x16 la0 = {0}, la1 = {0}, lb0 = {0}, lb1 = {0};
+    rows64_product<true>(la0, la1, img0, rb, ldsB, t, tinv + (int64_t)b * NB * NB, NB);
+    rows64_product<false>(lb0, lb1, img1, rb, ldsB, t, (const float*)nullptr, 0);
+    __syncthreads();                                                    // every wave has read X from the images
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int r = OISAT_PIECE_ROW(e);
+        X[(int64_t)r * ld + OISAT_PIECE_COL(0)] = la0[e];
+        X[(int64_t)r * ld + OISAT_PIECE_COL(1)] = la1[e];
+        X[(int64_t)(SB + r) * ld + OISAT_PIECE_COL(0)] = lb0[e];
+        X[(int64_t)(SB + r) * ld + OISAT_PIECE_COL(1)] = lb1[e];
+        img0[r * LDP + OISAT_PIECE_COL(0)] = la0[e];
+        img0[r * LDP + OISAT_PIECE_COL(1)] = la1[e];
+        img1[r * LDP + OISAT_PIECE_COL(0)] = lb0[e];
+        img1[r * LDP + OISAT_PIECE_COL(1)] = lb1[e];
+    }
+    __syncthreads();
+    // B operand of the second product = L21 itself: its K-chunks come from the images (row r of L21, the chunk's columns)
+    const int srow = t >> 3, sk = (t & 7) * 4;
+#define OISAT_LOAD_L21()                                                                                        \
+    do {                                                                                                        \
+        rb[0] = *reinterpret_cast<const v4f*>(&img0[srow * LDP + 0 * BK + sk]);                              \
+        rb[1] = *reinterpret_cast<const v4f*>(&img0[(srow + 32) * LDP + 0 * BK + sk]);                       \
+        rb[2] = *reinterpret_cast<const v4f*>(&img1[srow * LDP + 0 * BK + sk]);                              \
+        rb[3] = *reinterpret_cast<const v4f*>(&img1[(srow + 32) * LDP + 0 * BK + sk]);                       \
+        rb[4] = *reinterpret_cast<const v4f*>(&img0[srow * LDP + 1 * BK + sk]);                              \
+        rb[5] = *reinterpret_cast<const v4f*>(&img0[(srow + 32) * LDP + 1 * BK + sk]);                       \
+        rb[6] = *reinterpret_cast<const v4f*>(&img1[srow * LDP + 1 * BK + sk]);                              \
+        rb[7] = *reinterpret_cast<const v4f*>(&img1[(srow + 32) * LDP + 1 * BK + sk]);                       \
+        rb[8] = *reinterpret_cast<const v4f*>(&img0[srow * LDP + 2 * BK + sk]);                              \
+        rb[9] = *reinterpret_cast<const v4f*>(&img0[(srow + 32) * LDP + 2 * BK + sk]);                       \
+        rb[10] = *reinterpret_cast<const v4f*>(&img1[srow * LDP + 2 * BK + sk]);                             \
+        rb[11] = *reinterpret_cast<const v4f*>(&img1[(srow + 32) * LDP + 2 * BK + sk]);                      \
+        rb[12] = *reinterpret_cast<const v4f*>(&img0[srow * LDP + 3 * BK + sk]);                             \
+        rb[13] = *reinterpret_cast<const v4f*>(&img0[(srow + 32) * LDP + 3 * BK + sk]);                      \
+        rb[14] = *reinterpret_cast<const v4f*>(&img1[srow * LDP + 3 * BK + sk]);                             \
+        rb[15] = *reinterpret_cast<const v4f*>(&img1[(srow + 32) * LDP + 3 * BK + sk]);                      \
+    } while (0)
+    OISAT_LOAD_L21();
+    pair_mid_update(D, ld, img0, rb, ldsB, t, true);
+    OISAT_LOAD_L21();
+    pair_mid_update(D + (int64_t)SB * ld, ld, img1, rb, ldsB, t, false);
+#undef OISAT_LOAD_L21
+}
+#undef OISAT_PIECE_ROW
+#undef OISAT_PIECE_COL
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Factor and invert a 16x16 diagonal block in ONE sweep, in registers.  Lane r of every 16-lane row holds row r of the
@@ -1349,6 +1601,23 @@ int launch_gemm(oisat_ctx* h, const char* name, float* C, int64_t ldc, const flo
 // matrices that reach it (a prefix of the table), every launch covers all of them ------------------------------------------
 static inline int64_t tiles_lower(int64_t ntm, int64_t ntn) { return ntn * ntm - ntn * (ntn - 1) / 2; }
 
+// Leaves of the recursion are PAIRS of block columns (pair_mid_kernel / pair_panel_kernel) where the leaf-level launches
+// are bound by HBM traffic, i.e. in lock-step batches of many systems (>= OISAT_LEAF_PAIRS_MIN members, default 8; 0 = never):
+// a month's 48 tiles factor in 23.6 ms instead of 25.6.  For one system or a couple of polar caps the same launches are
+// latency-bound and the extra one-workgroup step between the two diagonal blocks costs more than the saved pass
+// (10,000 observations: 8.6 ms per analysis against 8.0), so those keep single-block leaves.
+static const int kLeafPairsMin = getenv("OISAT_LEAF_PAIRS_MIN") ? atoi(getenv("OISAT_LEAF_PAIRS_MIN")) : 8;
+static const bool kSinglePairs = getenv("OISAT_LEAF_PAIRS_SINGLE") && atoi(getenv("OISAT_LEAF_PAIRS_SINGLE")) != 0;
+// split point of the node [b0, b1): the left part gets ceil(half), rounded up to an even number of blocks when leaves are
+// pairs (so that the tree ends in pairs wherever it can); the one rule of potrf_rec, potrf_rec_batched and the tile tables
+static inline int64_t split_mid(int64_t b0, int64_t b1, bool pairs) {
+    const int64_t n = b1 - b0;
+    int64_t left = (n + 1) / 2;
+    if (pairs && n > 2 && (left & 1)) ++left;
+    if (left >= n) left = n - 1;
+    return b0 + left;
+}
+
 // node key of the compact-enumeration tables: kind 0 (b0, mid, b1) / kind 1 (b0)
 static inline long long cum_key_of(int kind, int b0, int mid, int b1) {
     return ((long long)kind << 60) | ((long long)b0 << 40) | ((long long)mid << 20) | (long long)b1;
@@ -1377,15 +1646,16 @@ static void build_cum_tables(ChBatch* bt, std::vector<int>& host) {
         bt->cum_total.push_back(acc);
     };
     struct Rec {
-        static void go(int b0, int b1, const decltype(add)& add) {
+        static void go(int b0, int b1, const decltype(add)& add, bool pairs) {
             if (b1 - b0 == 1) { add(1, b0, 0, 0); return; }
-            const int mid = b0 + (b1 - b0 + 1) / 2;
-            go(b0, mid, add);
+            if (b1 - b0 == 2 && pairs) return;                  // a leaf pair: its kernels enumerate their own workgroups
+            const int mid = (int)split_mid(b0, b1, pairs);
+            go(b0, mid, add, pairs);
             add(0, b0, mid, b1);
-            go(mid, b1, add);
+            go(mid, b1, add, pairs);
         }
     };
-    Rec::go(0, bt->max_mpb, add);
+    Rec::go(0, bt->max_mpb, add, bt->pairs);
     std::sort(keys.begin(), keys.end());
     std::vector<int> off, cnt, tot;
     for (auto& kv : keys) {
@@ -1473,7 +1743,28 @@ int potrf_rec_batched(oisat_ctx* h, const ChBatch& bt, int b0, int b1, int* info
                      (int64_t)b0 * NB, (float*)nullptr, info_dev, b0, (const BatchMat*)bt.table_dev, h->wave_prio);
         return launch_gemm_batched(h, "trsm_gemm", bt, BatchArgs{bt.table_dev, 1, b0, 0, 0}, NB, 1, 0);
     }
-    const int mid = b0 + (b1 - b0 + 1) / 2;
+    if (b1 - b0 == 2 && bt.pairs) {                         // leaf pair (b0, b0 + 1)
+        int cnt = 0, maxrows = 0;
+        for (const BatchMat& m : bt.table) {
+            if (m.mpb <= b0) break;
+            ++cnt;
+            if (m.mpb - b0 - 2 > maxrows) maxrows = m.mpb - b0 - 2;
+        }
+        if (cnt == 0) return OISAT_OK;
+        const BatchMat* tb = (const BatchMat*)bt.table_dev;
+        OISAT_LAUNCH(h, "potrf_diag", potrf_diag3_kernel, dim3((unsigned)cnt), dim3(D3_THREADS), 0, (float*)nullptr, (int64_t)0,
+                     (int64_t)b0 * NB, (float*)nullptr, info_dev, b0, tb, h->wave_prio);
+        OISAT_LAUNCH(h, "pair_mid", pair_mid_kernel<true>, dim3((unsigned)cnt), dim3(256), 0, (float*)nullptr, (int64_t)0, 0,
+                     (const float*)nullptr, b0, tb, h->wave_prio);
+        OISAT_LAUNCH(h, "potrf_diag", potrf_diag3_kernel, dim3((unsigned)cnt), dim3(D3_THREADS), 0, (float*)nullptr, (int64_t)0,
+                     (int64_t)(b0 + 1) * NB, (float*)nullptr, info_dev, b0 + 1, tb, h->wave_prio);
+        if (maxrows > 0) {
+            OISAT_LAUNCH(h, "pair_panel", pair_panel_kernel<true>, dim3((unsigned)(maxrows * 2), (unsigned)cnt), dim3(256), 0,
+                         (float*)nullptr, (int64_t)0, 0, (const float*)nullptr, b0, tb, h->wave_prio);
+        }
+        return OISAT_OK;
+    }
+    const int mid = (int)split_mid(b0, b1, bt.pairs);
     int rc = potrf_rec_batched(h, bt, b0, mid, info_dev);
     if (rc) return rc;
     rc = launch_gemm_batched(h, "syrk_gemm", bt, BatchArgs{bt.table_dev, 0, b0, mid, b1}, (mid - b0) * NB, 0, 1);
@@ -1506,7 +1797,21 @@ int potrf_rec(oisat_ctx* h, float* S, int64_t ld, int64_t mpb, int64_t b0, int64
         }
         return OISAT_OK;
     }
-    const int64_t mid = b0 + (b1 - b0 + 1) / 2;
+    if (b1 - b0 == 2 && kSinglePairs) {                     // leaf pair (b0, b0 + 1): OISAT_LEAF_PAIRS_SINGLE=1 (experiments)
+        OISAT_LAUNCH(h, "potrf_diag", potrf_diag3_kernel, dim3(1), dim3(D3_THREADS), 0, S, ld, b0 * NB, tinv, info_dev, (int)b0,
+                     (const BatchMat*)nullptr, 0);
+        OISAT_LAUNCH(h, "pair_mid", pair_mid_kernel<false>, dim3(1), dim3(256), 0, S, ld, (int)mpb, (const float*)tinv, (int)b0,
+                     (const BatchMat*)nullptr, 0);
+        OISAT_LAUNCH(h, "potrf_diag", potrf_diag3_kernel, dim3(1), dim3(D3_THREADS), 0, S, ld, (b0 + 1) * NB, tinv, info_dev,
+                     (int)(b0 + 1), (const BatchMat*)nullptr, 0);
+        const int64_t rows = mpb - b0 - 2;
+        if (rows > 0) {
+            OISAT_LAUNCH(h, "pair_panel", pair_panel_kernel<false>, dim3((unsigned)(rows * 2)), dim3(256), 0, S, ld, (int)mpb,
+                         (const float*)tinv, (int)b0, (const BatchMat*)nullptr, 0);
+        }
+        return OISAT_OK;
+    }
+    const int64_t mid = split_mid(b0, b1, kSinglePairs);
     int rc = potrf_rec(h, S, ld, mpb, b0, mid, tinv, info_dev);
     if (rc) return rc;
     // S[mid:, mid:b1] -= L[mid:, b0:mid] * L[mid:b1, b0:mid]^T   (region anchored on the diagonal)
@@ -1948,6 +2253,7 @@ extern "C" int oisat_batch_create(oisat_ctx* h, int nmat, float* const* S, const
         bt->table[i] = BatchMat{S[k], tinv[k], ld[k], m[k], (int)cdiv(m[k], NB), 0};
     }
     bt->max_mpb = bt->table[0].mpb;
+    bt->pairs = kLeafPairsMin > 0 && nmat >= kLeafPairsMin;
     if (hipMalloc(&bt->table_dev, sizeof(BatchMat) * nmat) != hipSuccess) {
         delete bt;
         oisat_set_error("oisat_batch_create: hipMalloc of the table failed");

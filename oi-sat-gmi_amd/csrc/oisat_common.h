@@ -53,6 +53,7 @@ struct ChBatch {                 // matrices factored in lock-step by oisat_batc
     std::vector<BatchMat> table;
     std::vector<int> order;      // table[i] is the caller's matrix order[i]
     int max_mpb = 0;
+    bool pairs = false;          // leaves of its recursion are pairs of block columns (many members: the leaf launches are HBM-bound)
 };
 
 struct oisat_ctx {

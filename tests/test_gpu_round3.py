@@ -229,3 +229,70 @@ def test_refinement_stops_at_its_tolerance(ctx):
     assert np.abs(out["default"][1] - out["all"][1]).max() <= 1e-6 * scale
     dz = np.abs(out["default"][2] - out["all"][2]).max() / np.abs(out["all"][2]).max()
     assert dz <= 1e-4, dz
+
+
+# ------------------------------------------------------------------------------------------------
+# lock-step batches of >= 8 systems factor with leaf PAIRS (pair_mid_kernel / pair_panel_kernel)
+# ------------------------------------------------------------------------------------------------
+def test_batched_factorization_with_leaf_pairs(ctx):
+    """oisat_batch_potrf on 10 systems (odd and even block counts, 1 .. 17 blocks): the recursion's leaves are pairs of
+    block columns -- one pass over the rows below for TRSM / rank-128 update / TRSM -- and every member's factor agrees
+    with oisat_potrf's (single-block leaves, another association of the same products) to fp32 rounding, solves through
+    oisat_potrs, and a non-positive-definite member is reported by index whether the bad pivot sits in the first or the
+    second block of a pair."""
+    from oisatgmi import dense
+    lib = ctx.lib
+    sizes = [2100, 1500, 1290, 1000, 777, 640, 300, 257, 129, 100]
+    mats, refs = [], []
+    for k, m in enumerate(sizes):
+        p = syn.point_obs_case(72, 144, m, 9100 + k)
+        cell = dense.regular_grid_cell(p.lat, p.lon, p.obs_lat, p.obs_lon)
+        mp = -(-m // 128) * 128
+        oxyz = ctx.upload(dense.unit_vectors(p.obs_lat, p.obs_lon))
+        osig = ctx.upload(np.sqrt(p.Sa.ravel())[cell], dtype=np.float64)
+        ovar = ctx.upload(p.obs_var, dtype=np.float64)
+        S1, S2 = ctx.alloc(mp * mp * 4), ctx.alloc(mp * mp * 4)
+        for S in (S1, S2):
+            ctx.check(lib.oisat_cov_build(ctx.h, oxyz.ptr, osig.ptr, ovar.ptr, m, dense.decay_constant(500.0), S.ptr, mp))
+        info = C.c_int(-1)
+        ctx.check(lib.oisat_potrf(ctx.h, S1.ptr, m, mp, C.byref(info)))
+        refs.append(ctx.download(S1.ptr, (mp, mp), np.float32))
+        mats.append((S2, ctx.alloc(mp * 128 * 4), m, mp))
+    n = len(mats)
+    Sp = (C.c_void_p * n)(*[a[0].ptr for a in mats])
+    Tp = (C.c_void_p * n)(*[a[1].ptr for a in mats])
+    mm = (C.c_int64 * n)(*[a[2] for a in mats])
+    ld = (C.c_int64 * n)(*[a[3] for a in mats])
+    bid = C.c_int(-1)
+    ctx.check(lib.oisat_batch_create(ctx.h, n, Sp, mm, ld, Tp, C.byref(bid)))
+    info2 = (C.c_int * 2)(-1, -1)
+    ctx.check(lib.oisat_batch_potrf(ctx.h, bid.value, info2))
+    assert list(info2) == [0, -1]
+    for (S2, T, m, mp), ref in zip(mats, refs):
+        got = ctx.download(S2.ptr, (mp, mp), np.float32)
+        assert np.isfinite(np.tril(got)).all()
+        assert np.abs(np.tril(got) - np.tril(ref)).max() <= 4e-6 * np.abs(np.tril(ref)).max(), m
+        ctx.check(lib.oisat_factor_adopt(ctx.h, S2.ptr, m, mp, T.ptr))
+        rhs = np.random.default_rng(m).normal(size=m)
+        zb = ctx.upload(rhs)
+        ctx.check(lib.oisat_potrs(ctx.h, S2.ptr, m, mp, zb.ptr))
+        z = ctx.download(zb.ptr, (m,), np.float64)
+        Lh = np.tril(ref[:m, :m]).astype(np.float64)
+        zr = np.linalg.solve(Lh @ Lh.T, rhs)
+        assert np.linalg.norm(z - zr) <= 1e-3 * np.linalg.norm(zr)
+    ctx.check(lib.oisat_batch_destroy(ctx.h, bid.value))
+    # bad pivots inside pairs: column 201 is in the second block of the pair (0, 1), column 300 in the first of (2, 3)
+    for col in (200, 299):
+        members = [(4.0 * np.eye(512) + 0.5).astype(np.float32) for _ in range(8)]
+        members[5][col, col] = -1.0
+        bufs = [ctx.upload(a) for a in members]
+        tinvs = [ctx.alloc(512 * 128 * 4) for _ in members]
+        Sp = (C.c_void_p * 8)(*[b.ptr for b in bufs])
+        Tp = (C.c_void_p * 8)(*[b.ptr for b in tinvs])
+        mm = (C.c_int64 * 8)(*[512] * 8)
+        ld = (C.c_int64 * 8)(*[512] * 8)
+        ctx.check(lib.oisat_batch_create(ctx.h, 8, Sp, mm, ld, Tp, C.byref(bid)))
+        with pytest.raises(_hip.OisatError, match=f"matrix 5 not positive definite at column {col + 1}"):
+            ctx.check(lib.oisat_batch_potrf(ctx.h, bid.value, info2))
+        ctx.solve_status(clear=True)
+        ctx.check(lib.oisat_batch_destroy(ctx.h, bid.value))
