@@ -1568,6 +1568,12 @@ int launch_gemm(oisat_ctx* h, const char* name, float* C, int64_t ldc, const flo
     const int ntm = (int)(M / NB), ntn = (int)(N / NB);
     const int64_t ntiles = lower ? (int64_t)ntn * ntm - (int64_t)ntn * (ntn - 1) / 2 : (int64_t)ntm * ntn;
     if (ntiles <= 0) return OISAT_OK;
+    static const bool detail = getenv("OISAT_PROF_DETAIL") && atoi(getenv("OISAT_PROF_DETAIL")) != 0;
+    char dname[64];
+    if (detail && h->prof) {                                // profiling aid: one record per launch shape
+        snprintf(dname, sizeof(dname), "%s K%d t%lld n1", name, K, (long long)ntiles);
+        name = dname;
+    }
     // too few 128x128 tiles for the 512 workgroup slots: 64x64 tiles, four workgroups per CU; the in-place TRSM form
     // (C aliases A, N == K == 128) takes 64 x 128 tiles (gemm_nt_rows64_kernel).
     static const int small_max = getenv("OISAT_SMALL_TILES") ? atoi(getenv("OISAT_SMALL_TILES")) : 700;
