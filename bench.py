@@ -67,7 +67,7 @@ def parse():
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--tier-a-only", action="store_true", help="run only the reference-parity (Tier-A) kernel legs (profiling aid)")
     ap.add_argument("--only", default="", help="profiling aid: comma list of legs to run INSTEAD of the whole bench -- tiled, "
-                    "secondary (config 2 alone), config4; prints {leg: result}")
+                    "secondary (config 2 alone), config4, pcie, regrid; prints {leg: result}")
     ap.add_argument("--no-config4", action="store_true", help="skip the fixed-workload strong-scaling leg (12 months x tiles)")
     ap.add_argument("--c4-months", type=int, default=12)
     ap.add_argument("--c4-passes", type=int, default=2)
@@ -655,6 +655,10 @@ def main():
                 res[leg] = {"ms_per_step": 1e3 * el2 / 20, "ms_per_step_refine1": 1e3 * el1 / 20, "refine": r2, "obs": plan2.m,
                             "roofline": roof2, "kernel_ms_per_step": per2}
                 del plan2
+            elif leg == "pcie":
+                res[leg] = pcie_leg(sync)
+            elif leg == "regrid":
+                res[leg] = regrid_leg(ctx, sync)
             elif leg == "config4":
                 lat2, lon2 = syn.global_grid(ny, nx)
                 res[leg] = config4_leg(ctx, args, 1, 0, local, lat2, lon2, sync, None)
