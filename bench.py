@@ -758,7 +758,7 @@ def main():
                 for q in bplans:
                     q.run_build(L2)
                 bf.run(bpool, [[q] for q in bplans], r2)
-                for l in blanes:
+                for l in blanes + bf.ctxs:               # the lock-step solves run on the group streams
                     l.sync()
             months_batched()
             for q in bplans:

@@ -377,6 +377,22 @@ int oisat_set_refine_tol(oisat_ctx* h, double tol);
 int oisat_batch_create(oisat_ctx* h, int nmat, float* const* S, const int64_t* m, const int64_t* ld, float* const* tinv,
                        int* batch_id_out);
 int oisat_batch_potrf(oisat_ctx* h, int batch_id, int* info_host);
+
+/* The solve phase of a batch in lock-step as well (round 3): after oisat_batch_set_solve has told the batch where every
+ * member keeps its observations, innovation, solution, work vectors and grid, oisat_batch_solve enqueues -- on the batch's
+ * handle, behind oisat_batch_potrf, no host hand-over -- the gain solve and the increment of ALL members with one launch
+ * per step: pad, forward / backward sweep (tickets over (member, block row), rows ascending, so the factors of all systems
+ * are streamed level by level), float64 residual, convergence test (per member, oisat_set_refine_tol), at most `refine`
+ * corrections, increment.  Per member the arithmetic is that of oisat_gain_solve + oisat_apply_increment.
+ * Arrays are indexed like those of oisat_batch_create.  work[i]: dev double[2 * roundup(m_i, 128)]; state[i]: dev, 256
+ * zeroed bytes; observations in ascending latitude (olat[i]); xa[i] | inc[i]: where the analysis and the increment of
+ * member i go (dtype of oisat_batch_solve). */
+int oisat_batch_set_solve(oisat_ctx* h, int batch_id, int nmat, const double* const* oxyz, const double* const* osig,
+                          const double* const* ovar, const double* const* d, const double* const* olat, double* const* z,
+                          double* const* work, void* const* state, const double* const* gxyz, const double* const* gsig,
+                          const double* const* glat, const int64_t* n, const void* const* xb, void* const* xa,
+                          void* const* inc);
+int oisat_batch_solve(oisat_ctx* h, int batch_id, int dtype, double g, int refine);
 int oisat_batch_destroy(oisat_ctx* h, int batch_id);
 int oisat_factor_adopt(oisat_ctx* h, const float* L, int64_t m, int64_t ld, float* tinv);
 

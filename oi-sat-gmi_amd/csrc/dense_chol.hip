@@ -1276,14 +1276,6 @@ struct TrsvCtl {                         // zero when a sweep starts: zeroed at 
     unsigned pad;
 };
 
-// state of one gain solve on the device (workspace slot 9): squared norms for the convergence test and the flag that
-// turns the remaining refinement launches into no-ops
-struct SolveState {
-    double dd;                           // |d|^2
-    double norm[12];                     // |r_k|^2, k = 0 .. refine
-    int conv;                            // set when |r_k| <= tol |d|: every later residual / sweep launch of this solve returns at once
-    int computed;                        // number of residual norms stored
-};
 
 // 256 threads: thread t moves 16 B at row (t>>5)+8p, column (t&31)*4 -> every row is one 512-B segment.
 // Macros, not functions: the 16 x float4 staging registers must stay in VGPRs (arrays passed by
@@ -1329,6 +1321,84 @@ __device__ __forceinline__ bool wait_payload(const double* src, double* vec, Trs
 // fewer, persistent workgroups would hold fewer of the slots the other group's GEMMs run on, but a row's producers are
 // then fetched one agent-scope round trip after the other instead of while waiting for its turn -- measured at 4 rows per
 // workgroup: 0.54 vs 0.25 ms per sweep at 10,000 observations, a localised month 73.3 vs 69.6 ms.
+// one block row of a sweep: claim order tk (0 .. nb-1) of ITS system; false = a producer never showed up (bounded spin)
+template <int TRANSPOSE>
+__device__ __forceinline__ bool trsv_row(const float* __restrict__ L, int64_t ld, const float* __restrict__ tinv, int nb, int tk,
+                                         double* __restrict__ rhs, double* __restrict__ sol, TrsvCtl* __restrict__ ctl,
+                                         unsigned* __restrict__ err_total, int two_tiles, double* __restrict__ zout, int64_t m,
+                                         int accumulate, float* __restrict__ tile, double* __restrict__ vec, double* __restrict__ part,
+                                         unsigned* __restrict__ s_ok) {
+    const int tid = threadIdx.x;
+    const int row = tid & (NB - 1), hf = tid >> 7;       // two threads per row: columns [64*hf, 64*hf+64)
+    float* const tileT = tile + NB * TLD;
+    const int b = TRANSPOSE ? nb - 1 - tk : tk;             // my block row (fwd) / block column (bwd)
+    double acc = 0.0;
+    if (hf == 0) {
+        // my block of the right-hand side is read by nobody else: take it and leave the "not yet published" pattern
+        // behind, so that the NEXT sweep (which publishes its solution into this vector) finds it prepared
+        acc = rhs[(int64_t)b * NB + row];
+        reinterpret_cast<unsigned long long*>(rhs)[(int64_t)b * NB + row] = kTrsvEmpty;
+    }
+    float4 reg[16];
+    const int nsteps = tk;                                  // producers: claim orders 0 .. tk-1
+    // step-th producer j = step (fwd) / nb-1-step (bwd); its block is L[b, j] (fwd, j < b) or L[j, b] (bwd, j > b)
+    const float* Tb = tinv + (int64_t)b * NB * NB;
+    const float* base = TRANSPOSE ? L + (int64_t)(nb - 1) * NB * ld + (int64_t)b * NB : L + (int64_t)b * NB * ld;
+    const int64_t hop = TRANSPOSE ? -(int64_t)NB * ld : (int64_t)NB;      // pointer step from one producer's block to the next
+    // two_tiles: T_b goes to a second LDS tile right away -- it depends on nobody -- so that the last pass finds it there
+    // instead of loading and staging it behind the last producer's hand-over
+    if (two_tiles) {
+        TILE_PREFETCH(Tb, NB)
+        float* tile = tileT;                                // TILE_STORE writes to the `tile` in scope
+        TILE_STORE()
+    }
+    if (nsteps > 0) { TILE_PREFETCH(base, ld) } else if (!two_tiles) { TILE_PREFETCH(Tb, NB) }
+    for (int step = 0; step <= nsteps; ++step) {
+        const bool last = step == nsteps;                   // last pass: multiply by the inverted diagonal block
+        if (!(last && two_tiles)) TILE_STORE()              // this step's block: in LDS before the wait, off the critical path
+        if (!last) {
+            const int j = TRANSPOSE ? nb - 1 - step : step;
+            if (!wait_payload(sol + (int64_t)j * NB, vec, ctl, err_total, tid, s_ok)) return false;
+            if (step + 1 < nsteps) { const float* nx = base + (int64_t)(step + 1) * hop; TILE_PREFETCH(nx, ld) }
+            else if (!two_tiles) { TILE_PREFETCH(Tb, NB) }
+        } else {
+            if (hf == 0) vec[row] = acc;
+            __syncthreads();
+        }
+        double u = 0.0;
+        const int c0 = hf * 64;
+        const float* blk = (last && two_tiles) ? tileT : tile;
+        if (!TRANSPOSE) {
+#pragma unroll 8
+            for (int c = c0; c < c0 + 64; ++c) u += (double)blk[row * TLD + c] * vec[c];       // row of the block
+        } else {
+#pragma unroll 8
+            for (int c = c0; c < c0 + 64; ++c) u += (double)blk[c * TLD + row] * vec[c];       // column of the block
+        }
+        if (hf == 1) part[row] = u;
+        __syncthreads();
+        if (hf == 0) {
+            if (!last) acc -= u + part[row];
+            else acc = u + part[row];
+        }
+    }
+    if (hf == 0) {
+        const int64_t i = (int64_t)b * NB + row;
+        __hip_atomic_store(&sol[i], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (zout != nullptr && i < m) zout[i] = accumulate ? zout[i] + acc : acc;       // the solve's result where the caller wants it
+    }
+    return true;
+}
+
+__device__ __forceinline__ void trsv_leave(TrsvCtl* __restrict__ ctl) {        // thread 0: the last workgroup to leave hands
+    const unsigned gone = __hip_atomic_fetch_add(&ctl->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // the block back clean
+    if (gone == gridDim.x - 1u) {
+        __hip_atomic_store(&ctl->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ctl->error, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ctl->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 template <int TRANSPOSE>
 __global__ __launch_bounds__(256) void trsv_pipe_kernel(const float* __restrict__ L, int64_t ld, const float* __restrict__ tinv, int nb,
                                                          double* __restrict__ rhs, double* __restrict__ sol,
@@ -1339,21 +1409,8 @@ __global__ __launch_bounds__(256) void trsv_pipe_kernel(const float* __restrict_
     __shared__ double vec[NB], part[NB];
     __shared__ unsigned s_ticket, s_ok;
     const int tid = threadIdx.x;
-    const int row = tid & (NB - 1), hf = tid >> 7;       // two threads per row: columns [64*hf, 64*hf+64)
     chain_prio();
     if (st != nullptr && st->conv != 0) return;          // refinement already converged: this sweep is not needed (block-uniform)
-    // the last workgroup to leave hands the control block back clean (ticket, error, done = 0): no memset per sweep
-    auto leave = [&]() {
-        if (tid == 0) {
-            const unsigned gone = __hip_atomic_fetch_add(&ctl->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (gone == gridDim.x - 1u) {
-                __hip_atomic_store(&ctl->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&ctl->error, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&ctl->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    };
-    float* const tileT = tile + NB * TLD;
     while (true) {
         __syncthreads();                                 // the previous row's LDS (vec, part, tiles, ticket) is no longer read
         if (tid == 0) {
@@ -1361,69 +1418,47 @@ __global__ __launch_bounds__(256) void trsv_pipe_kernel(const float* __restrict_
             s_ok = 1u;
         }
         __syncthreads();
-        const int tk = (int)s_ticket;                       // 0 .. nb-1 in claim order
+        const int tk = (int)s_ticket;                    // 0 .. nb-1 in claim order
         if (tk >= nb) break;
-        const int b = TRANSPOSE ? nb - 1 - tk : tk;         // my block row (fwd) / block column (bwd)
-        double acc = 0.0;
-        if (hf == 0) {
-            // my block of the right-hand side is read by nobody else: take it and leave the "not yet published" pattern
-            // behind, so that the NEXT sweep (which publishes its solution into this vector) finds it prepared
-            acc = rhs[(int64_t)b * NB + row];
-            reinterpret_cast<unsigned long long*>(rhs)[(int64_t)b * NB + row] = kTrsvEmpty;
-        }
-        float4 reg[16];
-        const int nsteps = tk;                              // producers: tickets 0 .. tk-1
-        // step-th producer j = step (fwd) / nb-1-step (bwd); its block is L[b, j] (fwd, j < b) or L[j, b] (bwd, j > b)
-        const float* Tb = tinv + (int64_t)b * NB * NB;
-        const float* base = TRANSPOSE ? L + (int64_t)(nb - 1) * NB * ld + (int64_t)b * NB : L + (int64_t)b * NB * ld;
-        const int64_t hop = TRANSPOSE ? -(int64_t)NB * ld : (int64_t)NB;      // pointer step from one producer's block to the next
-        // two_tiles: T_b goes to a second LDS tile right away -- it depends on nobody -- so that the last pass finds it there
-        // instead of loading and staging it behind the last producer's hand-over
-        if (two_tiles) {
-            TILE_PREFETCH(Tb, NB)
-            float* tile = tileT;                            // TILE_STORE writes to the `tile` in scope
-            TILE_STORE()
-        }
-        if (nsteps > 0) { TILE_PREFETCH(base, ld) } else if (!two_tiles) { TILE_PREFETCH(Tb, NB) }
-        for (int step = 0; step <= nsteps; ++step) {
-            const bool last = step == nsteps;               // last pass: multiply by the inverted diagonal block
-            if (!(last && two_tiles)) TILE_STORE()          // this step's block: in LDS before the wait, off the critical path
-            if (!last) {
-                const int j = TRANSPOSE ? nb - 1 - step : step;
-                if (!wait_payload(sol + (int64_t)j * NB, vec, ctl, err_total, tid, &s_ok)) {
-                    leave();
-                    return;
-                }
-                if (step + 1 < nsteps) { const float* nx = base + (int64_t)(step + 1) * hop; TILE_PREFETCH(nx, ld) }
-                else if (!two_tiles) { TILE_PREFETCH(Tb, NB) }
-            } else {
-                if (hf == 0) vec[row] = acc;
-                __syncthreads();
-            }
-            double u = 0.0;
-            const int c0 = hf * 64;
-            const float* blk = (last && two_tiles) ? tileT : tile;
-            if (!TRANSPOSE) {
-#pragma unroll 8
-                for (int c = c0; c < c0 + 64; ++c) u += (double)blk[row * TLD + c] * vec[c];       // row of the block
-            } else {
-#pragma unroll 8
-                for (int c = c0; c < c0 + 64; ++c) u += (double)blk[c * TLD + row] * vec[c];       // column of the block
-            }
-            if (hf == 1) part[row] = u;
-            __syncthreads();
-            if (hf == 0) {
-                if (!last) acc -= u + part[row];
-                else acc = u + part[row];
-            }
-        }
-        if (hf == 0) {
-            const int64_t i = (int64_t)b * NB + row;
-            __hip_atomic_store(&sol[i], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (zout != nullptr && i < m) zout[i] = accumulate ? zout[i] + acc : acc;   // the solve's result where the caller wants it
-        }
+        if (!trsv_row<TRANSPOSE>(L, ld, tinv, nb, tk, rhs, sol, ctl, err_total, two_tiles, zout, m, accumulate, tile, vec, part, &s_ok))
+            break;
     }
-    leave();
+    if (tid == 0) trsv_leave(ctl);
+}
+
+// The sweeps of MANY systems in one launch (oisat_batch_solve): tickets run over the list `ord` of (member, step) pairs,
+// steps ascending -- step k of every system before step k+1 of any -- so a row still waits for lower tickets only, and the
+// launch streams the factors of all systems level by level instead of one latency-bound chain per system and lane.
+// A member whose refinement has converged is skipped row by row (nobody waits for its rows).
+template <int TRANSPOSE>
+__global__ __launch_bounds__(256) void trsv_batched_kernel(const SolveMember* __restrict__ mem, const int* __restrict__ ord, int total,
+                                                            TrsvCtl* __restrict__ ctl, unsigned* __restrict__ err_total,
+                                                            int first_solve, int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];        // [128][TLD]
+    __shared__ double vec[NB], part[NB];
+    __shared__ unsigned s_ticket, s_ok;
+    const int tid = threadIdx.x;
+    chain_prio();
+    while (true) {
+        __syncthreads();
+        if (tid == 0) {
+            s_ticket = atomicAdd(&ctl->ticket, 1u);
+            s_ok = 1u;
+        }
+        __syncthreads();
+        const unsigned t = s_ticket;
+        if (t >= (unsigned)total) break;
+        const int e = ord[t];
+        const SolveMember* mb = mem + (e >> 12);
+        const int tk = e & 4095;
+        if (!first_solve && mb->st->conv != 0) continue;             // this system needs no further correction
+        double* in = TRANSPOSE ? mb->fwd : mb->rhs;
+        double* out = TRANSPOSE ? mb->rhs : mb->fwd;
+        if (!trsv_row<TRANSPOSE>(mb->S, mb->ld, mb->tinv, mb->mpb, tk, in, out, ctl, err_total, 0, TRANSPOSE ? mb->z : (double*)nullptr,
+                                 mb->m, accumulate, tile, vec, part, &s_ok))
+            break;
+    }
+    if (tid == 0) trsv_leave(ctl);
 }
 
 // rhs <- src padded with zeros to mp, fwd <- the "not yet published" pattern; resets the solve's convergence state
@@ -1938,6 +1973,55 @@ int status_ws(oisat_ctx* h, int** info_dev, char** trsv_base) {
     return OISAT_OK;
 }
 
+__global__ __launch_bounds__(256) void solve_prep_batched_kernel(const SolveMember* __restrict__ mem) {
+    const SolveMember* mb = mem + blockIdx.y;
+    const int64_t m = mb->m, mp = (int64_t)mb->mpb * NB;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t g0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const double* src = mb->d;
+    double* rhs = mb->rhs;
+    unsigned long long* fwd = reinterpret_cast<unsigned long long*>(mb->fwd);
+    for (int64_t i = g0; i < mp; i += stride) {
+        rhs[i] = i < m ? src[i] : 0.0;
+        fwd[i] = kTrsvEmpty;
+    }
+    if (g0 == 0) {
+        mb->st->conv = 0;
+        mb->st->computed = 0;
+    }
+}
+
+__global__ __launch_bounds__(1024) void resid_check_batched_kernel(const SolveMember* __restrict__ mem, int k, double tol2) {
+    __shared__ double sr[1024], sd[1024];
+    const SolveMember* mb = mem + blockIdx.x;
+    SolveState* st = mb->st;
+    if (st->conv != 0) return;
+    const double* r = mb->rhs;
+    const double* d = mb->d;
+    const int64_t m = mb->m;
+    double a = 0.0, b = 0.0;
+    for (int64_t i = threadIdx.x; i < m; i += 1024) {
+        a += r[i] * r[i];
+        if (k == 0) b += d[i] * d[i];
+    }
+    sr[threadIdx.x] = a;
+    sd[threadIdx.x] = b;
+    __syncthreads();
+    for (int q = 512; q > 0; q >>= 1) {
+        if ((int)threadIdx.x < q) {
+            sr[threadIdx.x] += sr[threadIdx.x + q];
+            sd[threadIdx.x] += sd[threadIdx.x + q];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (k == 0) st->dd = sd[0];
+        st->norm[k] = sr[0];
+        st->computed = k + 1;
+        if (sr[0] <= tol2 * st->dd) st->conv = 1;
+    }
+}
+
 // L L^T x = rhs: forward sweep rhs -> fwd, backward sweep fwd -> rhs (the solution, padded).  On entry `fwd` must hold the
 // "not yet published" pattern (solve_prep_kernel, or the previous solve's backward sweep, which leaves it behind); each
 // sweep re-arms the vector it has consumed for the sweep that follows, and the last workgroup of a sweep zeroes its
@@ -1996,6 +2080,12 @@ hipError_t dense_kernel_attributes() {
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)trsv_pipe_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)(sizeof(float) * NB * TLD * 2));
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)trsv_batched_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(sizeof(float) * NB * TLD));
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)trsv_batched_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(sizeof(float) * NB * TLD));
         if (e == hipSuccess) {
             const char* env = getenv("OISAT_CHAIN_PRIO");
             const int prio = env ? atoi(env) : 0;
@@ -2311,9 +2401,100 @@ extern "C" int oisat_batch_destroy(oisat_ctx* h, int batch_id) {
     ChBatch* bt = h->batches[batch_id];
     if (bt->table_dev) HIP_TRY(hipFree(bt->table_dev));
     if (bt->cum_dev) HIP_TRY(hipFree(bt->cum_dev));
+    if (bt->solve_dev) HIP_TRY(hipFree(bt->solve_dev));
+    if (bt->ord_dev) HIP_TRY(hipFree(bt->ord_dev));
+    if (bt->ctl_dev) HIP_TRY(hipFree(bt->ctl_dev));
     delete bt;
     h->batches[batch_id] = nullptr;
     return OISAT_OK;
+}
+
+int oisat_cov_residual_batched(oisat_ctx* h, const SolveMember* mem_dev, int nmem, int64_t max_m, double g);
+int oisat_apply_increment_batched(oisat_ctx* h, int dtype, const SolveMember* mem_dev, int nmem, int64_t max_n, double g);
+
+extern "C" int oisat_batch_set_solve(oisat_ctx* h, int batch_id, int nmat, const double* const* oxyz, const double* const* osig,
+                                     const double* const* ovar, const double* const* d, const double* const* olat, double* const* z,
+                                     double* const* work, void* const* state, const double* const* gxyz, const double* const* gsig,
+                                     const double* const* glat, const int64_t* n, const void* const* xb, void* const* xa,
+                                     void* const* inc) {
+    ARG_CHECK(h && batch_id >= 0 && batch_id < (int)h->batches.size() && h->batches[batch_id]);
+    ChBatch* bt = h->batches[batch_id];
+    ARG_CHECK(nmat == (int)bt->table.size());
+    ARG_CHECK(oxyz && osig && ovar && d && olat && z && work && state && gxyz && gsig && glat && n && xb && xa && inc);
+    std::vector<SolveMember> mem(nmat);
+    std::vector<int> ord;
+    bt->max_m = bt->max_n = bt->max_mp = 0;
+    for (int i = 0; i < nmat; ++i) {                         // table order (largest first); order[i] = the caller's index
+        const int c = bt->order[i];
+        const BatchMat& bm = bt->table[i];
+        ARG_CHECK(oxyz[c] && osig[c] && ovar[c] && d[c] && olat[c] && z[c] && work[c] && state[c] && gxyz[c] && gsig[c] && glat[c]);
+        ARG_CHECK(n[c] > 0 && xb[c] && (xa[c] || inc[c]) && bm.mpb < 4096);
+        SolveMember& sm = mem[i];
+        sm.S = bm.S; sm.tinv = bm.tinv; sm.ld = bm.ld; sm.m = bm.m; sm.mpb = bm.mpb; sm.pad = 0;
+        sm.oxyz = oxyz[c]; sm.osig = osig[c]; sm.ovar = ovar[c]; sm.d = d[c]; sm.olat = olat[c];
+        sm.z = z[c]; sm.rhs = work[c]; sm.fwd = work[c] + (int64_t)bm.mpb * NB; sm.st = (SolveState*)state[c];
+        sm.gxyz = gxyz[c]; sm.gsig = gsig[c]; sm.glat = glat[c]; sm.n = n[c]; sm.xb = xb[c]; sm.xa = xa[c]; sm.inc = inc[c];
+        if (bm.m > bt->max_m) bt->max_m = bm.m;
+        if (n[c] > bt->max_n) bt->max_n = n[c];
+        if ((int64_t)bm.mpb * NB > bt->max_mp) bt->max_mp = (int64_t)bm.mpb * NB;
+    }
+    // ticket -> (member, step): steps ascending, members in table order inside a step (a prefix: sorted by block count)
+    for (int k = 0; k < bt->max_mpb; ++k)
+        for (int i = 0; i < nmat && bt->table[i].mpb > k; ++i) ord.push_back((i << 12) | k);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (bt->solve_dev) HIP_TRY(hipFree(bt->solve_dev));
+    if (bt->ord_dev) HIP_TRY(hipFree(bt->ord_dev));
+    if (bt->ctl_dev) HIP_TRY(hipFree(bt->ctl_dev));
+    bt->solve_dev = nullptr; bt->ord_dev = nullptr; bt->ctl_dev = nullptr;
+    HIP_TRY(hipMalloc((void**)&bt->solve_dev, sizeof(SolveMember) * nmat));
+    HIP_TRY(hipMalloc((void**)&bt->ord_dev, sizeof(int) * ord.size()));
+    HIP_TRY(hipMalloc(&bt->ctl_dev, 2 * kCtlBytes));
+    HIP_TRY(hipMemcpy(bt->solve_dev, mem.data(), sizeof(SolveMember) * nmat, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(bt->ord_dev, ord.data(), sizeof(int) * ord.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(bt->ctl_dev, 0, 2 * kCtlBytes));
+    bt->ord_total = (int)ord.size();
+    return OISAT_OK;
+}
+
+// the gain solve + increment of every member, each launch covering all of them (same arithmetic per member as
+// oisat_gain_solve + oisat_apply_increment; same stopping rule, per member)
+extern "C" int oisat_batch_solve(oisat_ctx* h, int batch_id, int dtype, double g, int refine) {
+    ARG_CHECK(h && batch_id >= 0 && batch_id < (int)h->batches.size() && h->batches[batch_id]);
+    ChBatch& bt = *h->batches[batch_id];
+    ARG_CHECK(bt.solve_dev != nullptr && bt.ord_total > 0 && refine >= 0 && refine <= 8 && g >= 0.0);
+    ARG_CHECK(dtype == OISAT_F32 || dtype == OISAT_F64);
+    char* base = nullptr;
+    if (int rc = status_ws(h, nullptr, &base)) return rc;
+    HIP_TRY(dense_kernel_attributes());
+    unsigned* err_total = (unsigned*)base;
+    const int nmem = (int)bt.table.size();
+    const SolveMember* mem = bt.solve_dev;
+    TrsvCtl* ctl_f = (TrsvCtl*)bt.ctl_dev;
+    TrsvCtl* ctl_b = (TrsvCtl*)((char*)bt.ctl_dev + kCtlBytes);
+    const size_t shm = sizeof(float) * NB * TLD;
+    // persistent workgroups: two per CU (66 KB of LDS each) or one per row if there are fewer rows
+    const int slots = 2 * (h->cu_count > 0 ? h->cu_count : 256);
+    const int grid = bt.ord_total < slots ? bt.ord_total : slots;
+    const double tol = h->refine_tol;
+    OISAT_LAUNCH(h, "copy_pad", solve_prep_batched_kernel, dim3((unsigned)stream_grid(bt.max_mp, 256) > 64u ? 64u : (unsigned)stream_grid(bt.max_mp, 256), (unsigned)nmem),
+                 dim3(256), 0, mem);
+    auto sweeps = [&](int first, int accumulate) -> int {
+        OISAT_LAUNCH(h, "trsv_fwd", (trsv_batched_kernel<0>), dim3(grid), dim3(256), shm, mem, (const int*)bt.ord_dev, bt.ord_total, ctl_f,
+                     err_total, first, 0);
+        OISAT_LAUNCH(h, "trsv_bwd", (trsv_batched_kernel<1>), dim3(grid), dim3(256), shm, mem, (const int*)bt.ord_dev, bt.ord_total, ctl_b,
+                     err_total, first, accumulate);
+        return OISAT_OK;
+    };
+    int rc = sweeps(1, 0);
+    if (rc) return rc;
+    for (int it = 0; it < refine; ++it) {
+        rc = oisat_cov_residual_batched(h, mem, nmem, bt.max_m, g);
+        if (rc) return rc;
+        OISAT_LAUNCH(h, "resid_check", resid_check_batched_kernel, dim3((unsigned)nmem), dim3(1024), 0, mem, it, tol * tol);
+        rc = sweeps(0, 1);
+        if (rc) return rc;
+    }
+    return oisat_apply_increment_batched(h, dtype, mem, nmem, bt.max_n, g);
 }
 
 extern "C" int oisat_batch_potrf(oisat_ctx* h, int batch_id, int* info_host) {

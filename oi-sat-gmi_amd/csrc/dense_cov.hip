@@ -87,11 +87,25 @@ __device__ __forceinline__ int64_t lower_bound_lat(const double* __restrict__ a,
 // Block = 64 rows; 256 threads = 64 rows x 4 column phases; fixed-order combine (deterministic).
 // olat (optional): latitudes of the observations in degrees, ASCENDING -- the block's rows then span
 // [olat[row0], olat[row_last]] and only columns inside that span +/- the window are visited.
+template <bool BATCH>
 __global__ __launch_bounds__(256) void cov_residual_kernel(const double* __restrict__ oxyz, const double* __restrict__ osig,
                                                             const double* __restrict__ ovar, int64_t m, double g,
                                                             const double* __restrict__ d, const double* __restrict__ z,
                                                             double* __restrict__ r, const double* __restrict__ olat, double win_deg,
-                                                            const int* __restrict__ converged) {
+                                                            const int* __restrict__ converged, const SolveMember* __restrict__ mem) {
+    if (BATCH) {                                                // batched: blockIdx.y = member, r = its padded right-hand side
+        const SolveMember* mb = mem + blockIdx.y;
+        m = mb->m;
+        if ((int64_t)blockIdx.x * 64 >= m) return;
+        oxyz = mb->oxyz;
+        osig = mb->osig;
+        ovar = mb->ovar;
+        d = mb->d;
+        z = mb->z;
+        r = mb->rhs;
+        if (olat != nullptr) olat = mb->olat;                   // (olat non-null = "use the latitude window")
+        converged = &mb->st->conv;
+    }
     __shared__ double sx[256], sy[256], sz[256], sw[256];      // chunk of 256 columns: coords and sig*z
     __shared__ double part[4][64];
     if (converged != nullptr && *converged != 0) return;       // the refinement has met its tolerance: nothing left to evaluate
@@ -140,14 +154,29 @@ __global__ __launch_bounds__(256) void cov_residual_kernel(const double* __restr
 // CDNA4, so this costs a few extra issue slots per pair, not a factor.  exp2 stays fp32 (v_exp_f32); the
 // product with sig*z and the running sum are double, because the terms cancel: sum|term| reaches several
 // hundred times the field scale at swath densities, so fp32 partial sums alone cost ~1e-5.
-template <typename T, int CELLS>
+template <typename T, int CELLS, bool BATCH>
 __global__ __launch_bounds__(256) void apply_increment_kernel(const double* __restrict__ gxyz, const double* __restrict__ gsig,
                                                                int64_t n, const double* __restrict__ oxyz,
                                                                const double* __restrict__ osig, const double* __restrict__ z,
                                                                int64_t m, float g2,
                                                                const T* __restrict__ xb, T* __restrict__ xa, T* __restrict__ inc,
                                                                const double* __restrict__ glat, const double* __restrict__ olat,
-                                                               double win_deg) {
+                                                               double win_deg, const SolveMember* __restrict__ mem) {
+    if (BATCH) {                                                // batched: blockIdx.y = member
+        const SolveMember* mb = mem + blockIdx.y;
+        n = mb->n;
+        if ((int64_t)blockIdx.x * CELLS * 256 >= n) return;
+        gxyz = mb->gxyz;
+        gsig = mb->gsig;
+        oxyz = mb->oxyz;
+        osig = mb->osig;
+        z = mb->z;
+        m = mb->m;
+        xb = (const T*)mb->xb;
+        xa = (T*)mb->xa;
+        inc = (T*)mb->inc;
+        if (glat != nullptr) { glat = mb->glat; olat = mb->olat; }      // (non-null = "use the latitude window")
+    }
     constexpr int CH = 512;
     __shared__ double2 sxy[CH], szw[CH];                    // (x, y) and (z, sig*z_solve)
     __shared__ double s_lo[4], s_hi[4];
@@ -248,8 +277,8 @@ int oisat_cov_residual_if(oisat_ctx* h, const double* oxyz, const double* osig, 
                           const double* d, const double* z, double* r_out, const double* olat_sorted, const int* converged_dev) {
     ARG_CHECK(h && oxyz && osig && ovar && d && z && r_out && m > 0);
     const double win = lat_window_deg(g * (double)kLog2e);
-    OISAT_LAUNCH(h, "cov_residual", cov_residual_kernel, dim3((unsigned)cdiv(m, 64)), dim3(256), 0, oxyz, osig, ovar, m, g, d,
-                 z, r_out, win < 180.0 ? olat_sorted : (const double*)nullptr, win, converged_dev);
+    OISAT_LAUNCH(h, "cov_residual", cov_residual_kernel<false>, dim3((unsigned)cdiv(m, 64)), dim3(256), 0, oxyz, osig, ovar, m, g, d,
+                 z, r_out, win < 180.0 ? olat_sorted : (const double*)nullptr, win, converged_dev, (const SolveMember*)nullptr);
     return OISAT_OK;
 }
 
@@ -270,11 +299,44 @@ extern "C" int oisat_apply_increment(oisat_ctx* h, int dtype, const double* gxyz
     const double win = lat_window_deg((double)g2);
     if (!(win < 180.0) || !glat || !olat_sorted) { glat = nullptr; olat_sorted = nullptr; }
     if (dtype == OISAT_F32) {
-        OISAT_LAUNCH(h, "apply_increment", (apply_increment_kernel<float, CELLS>), dim3(grid), dim3(256), 0, gxyz, gsig, n, oxyz,
-                     osig, z, m, g2, (const float*)xb, (float*)xa, (float*)inc, glat, olat_sorted, win);
+        OISAT_LAUNCH(h, "apply_increment", (apply_increment_kernel<float, CELLS, false>), dim3(grid), dim3(256), 0, gxyz, gsig, n, oxyz,
+                     osig, z, m, g2, (const float*)xb, (float*)xa, (float*)inc, glat, olat_sorted, win, (const SolveMember*)nullptr);
     } else {
-        OISAT_LAUNCH(h, "apply_increment", (apply_increment_kernel<double, CELLS>), dim3(grid), dim3(256), 0, gxyz, gsig, n,
-                     oxyz, osig, z, m, g2, (const double*)xb, (double*)xa, (double*)inc, glat, olat_sorted, win);
+        OISAT_LAUNCH(h, "apply_increment", (apply_increment_kernel<double, CELLS, false>), dim3(grid), dim3(256), 0, gxyz, gsig, n,
+                     oxyz, osig, z, m, g2, (const double*)xb, (double*)xa, (double*)inc, glat, olat_sorted, win,
+                     (const SolveMember*)nullptr);
+    }
+    return OISAT_OK;
+}
+
+// ---- batched forms (oisat_batch_solve, dense_chol.hip): blockIdx.y = member of the device table --------------------------
+int oisat_cov_residual_batched(oisat_ctx* h, const SolveMember* mem_dev, int nmem, int64_t max_m, double g) {
+    const double win = lat_window_deg(g * (double)kLog2e);
+    static const double dummy = 0.0;                        // non-null marker: "use each member's latitude window"
+    OISAT_LAUNCH(h, "cov_residual", cov_residual_kernel<true>, dim3((unsigned)cdiv(max_m, 64), (unsigned)nmem), dim3(256), 0,
+                 (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, (int64_t)0, g, (const double*)nullptr,
+                 (const double*)nullptr, (double*)nullptr, win < 180.0 ? &dummy : (const double*)nullptr, win, (const int*)nullptr,
+                 mem_dev);
+    return OISAT_OK;
+}
+
+int oisat_apply_increment_batched(oisat_ctx* h, int dtype, const SolveMember* mem_dev, int nmem, int64_t max_n, double g) {
+    constexpr int CELLS = 2;
+    const unsigned gx = (unsigned)cdiv(max_n, 256 * CELLS);
+    const float g2 = (float)(g * (double)kLog2e);
+    const double win = lat_window_deg((double)g2);
+    static const double dummy = 0.0;
+    const double* use = win < 180.0 ? &dummy : (const double*)nullptr;
+    if (dtype == OISAT_F32) {
+        OISAT_LAUNCH(h, "apply_increment", (apply_increment_kernel<float, CELLS, true>), dim3(gx, (unsigned)nmem), dim3(256), 0,
+                     (const double*)nullptr, (const double*)nullptr, (int64_t)0, (const double*)nullptr, (const double*)nullptr,
+                     (const double*)nullptr, (int64_t)0, g2, (const float*)nullptr, (float*)nullptr, (float*)nullptr, use, use, win,
+                     mem_dev);
+    } else {
+        OISAT_LAUNCH(h, "apply_increment", (apply_increment_kernel<double, CELLS, true>), dim3(gx, (unsigned)nmem), dim3(256), 0,
+                     (const double*)nullptr, (const double*)nullptr, (int64_t)0, (const double*)nullptr, (const double*)nullptr,
+                     (const double*)nullptr, (int64_t)0, g2, (const double*)nullptr, (double*)nullptr, (double*)nullptr, use, use,
+                     win, mem_dev);
     }
     return OISAT_OK;
 }

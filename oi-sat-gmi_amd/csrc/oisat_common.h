@@ -43,6 +43,30 @@ struct BatchMat {                // one matrix of a batched factorization (devic
     int pad;
 };
 
+// state of one gain solve on the device: squared norms for the convergence test and the flag that turns the remaining
+// refinement launches into no-ops (workspace slot 9 of a handle, or one 256-byte block per member of a batched solve)
+struct SolveState {
+    double dd;                   // |d|^2
+    double norm[12];             // |r_k|^2, k = 0 .. refine
+    int conv;                    // set when |r_k| <= tol |d|: every later residual / sweep launch of this solve returns at once
+    int computed;                // number of residual norms stored
+};
+
+struct SolveMember {             // one system of a batched solve phase (device table, oisat_batch_set_solve)
+    const float* S;              // its factor (after oisat_batch_potrf) and inverted diagonal blocks
+    const float* tinv;
+    int64_t ld, m;
+    int mpb, pad;
+    const double *oxyz, *osig, *ovar, *d, *olat;       // observations (ascending latitude), innovation
+    double *z, *rhs, *fwd;       // solution; padded right-hand side and forward solution [mpb * 128] each
+    SolveState* st;
+    const double *gxyz, *gsig, *glat;                   // the system's grid cells
+    int64_t n;
+    const void* xb;              // background, analysis, increment (dtype of the batch)
+    void* xa;
+    void* inc;
+};
+
 struct ChBatch {                 // matrices factored in lock-step by oisat_batch_potrf (sorted by block count, largest first)
     BatchMat* table_dev = nullptr;
     // compact tile enumeration of the persistent GEMM launches: for every node of the recursion tree the prefix sums of
@@ -53,6 +77,13 @@ struct ChBatch {                 // matrices factored in lock-step by oisat_batc
     std::vector<BatchMat> table;
     std::vector<int> order;      // table[i] is the caller's matrix order[i]
     int max_mpb = 0;
+    // batched solve phase (oisat_batch_set_solve): member table in the order of `table`, the sweep's ticket -> (member, step)
+    // list (steps ascending, so that a row only waits for lower tickets) and two control blocks (forward | backward)
+    SolveMember* solve_dev = nullptr;
+    int* ord_dev = nullptr;
+    void* ctl_dev = nullptr;
+    int ord_total = 0;
+    int64_t max_m = 0, max_n = 0, max_mp = 0;
     bool pairs = false;          // leaves of its recursion are pairs of block columns (many members: the leaf launches are HBM-bound)
 };
 

@@ -62,6 +62,9 @@ extern "C" void oisat_shutdown(oisat_ctx* h) {
         if (b) {
             if (b->table_dev) (void)hipFree(b->table_dev);
             if (b->cum_dev) (void)hipFree(b->cum_dev);
+            if (b->solve_dev) (void)hipFree(b->solve_dev);
+            if (b->ord_dev) (void)hipFree(b->ord_dev);
+            if (b->ctl_dev) (void)hipFree(b->ctl_dev);
             delete b;
         }
     delete h;

@@ -102,6 +102,12 @@ class DenseAnalysis:
         # batched factorization (BatchedFactor): the inverted diagonal blocks live in a buffer of this plan, not in the
         # handle's workspace, because many plans of one handle are factored at the same time
         self.tinv = c.alloc(self.mp_max * NB * 4).shared_with_other_streams() if batched else None
+        # ... and so do the work vectors and the convergence state of its gain solve (oisat_batch_solve runs on the group's stream)
+        self.work = c.alloc(2 * self.mp_max * 8).shared_with_other_streams() if batched else None
+        self.state = None
+        if batched:
+            self.state = c.alloc(256).shared_with_other_streams()
+            c.check(c.lib.oisat_memset(c.h, self.state.ptr, 0, 256))
         self.m = 0
         self._direct_innovation = False
         # every internal workspace of the solve is sized here, so that run() never allocates (include/oisat.h)
@@ -310,6 +316,10 @@ class BatchedFactor:
         # 720x1440 month the two polar caps (137 diagonal blocks each) are the critical path and used to sit idle for
         # 9 ms of a 73 ms span behind the tile group's first launches (profiles/r02_e_tiled_phases.txt); "smallest" is
         # round 2's order.  Whatever the order, a group's solves are released when THAT group is factored (run() polls).
+        # OISAT_BATCH_SOLVE=1 (default): the gain solves and increments of a group run in lock-step on the group's stream right
+        # behind its factorization (oisat_batch_solve); 0: round 2's form -- the host waits for the group and enqueues every
+        # plan's solve on its lane
+        self.batched_solve = os.environ.get("OISAT_BATCH_SOLVE", "1") != "0" and all(p.work is not None for p in order)
         self.order = os.environ.get("OISAT_BATCH_ORDER", "largest")
         self.groups = groups if self.order == "largest" else groups[::-1]
         # schedule (OISAT_BATCH_SCHEDULE): "overlap" (default) -- one stream per group, all groups side by side;
@@ -341,6 +351,15 @@ class BatchedFactor:
             bid = C.c_int(-1)
             ctx.check(ctx.lib.oisat_batch_create(ctx.h, n, Sp, mm, ld, Tp, C.byref(bid)))
             self.ids.append(bid.value)
+            if self.batched_solve:                          # the solve phase in lock-step too: tell the batch where everything lives
+                item = g[0].dt.itemsize
+                arr = lambda vals: (C.c_void_p * n)(*vals)      # noqa: E731
+                ctx.check(ctx.lib.oisat_batch_set_solve(
+                    ctx.h, bid.value, n, arr([p.oxyz.ptr for p in g]), arr([p.osig.ptr for p in g]), arr([p.ovar.ptr for p in g]),
+                    arr([p.d.ptr for p in g]), arr([p.olat.ptr for p in g]), arr([p.z.ptr for p in g]),
+                    arr([p.work.ptr for p in g]), arr([p.state.ptr for p in g]), arr([p.gxyz.ptr for p in g]),
+                    arr([p.gsig.ptr for p in g]), arr([p.glat.ptr for p in g]), (C.c_int64 * n)(*[p.n for p in g]),
+                    arr([p.xb_ptr for p in g]), arr([p.out_ptr for p in g]), arr([p.out_ptr + p.n * item for p in g])))
         self.group_of = {id(p): gi for gi, g in enumerate(self.groups) for p in g}
         self._threads = None
         # measured, one box (1 month of 720x1440 / 1e5 obs; a rank's eighth of 12 months; all 12 months):
@@ -366,6 +385,9 @@ class BatchedFactor:
                 ctx.wait_for(self.ctxs[gi - 1])             # one parked queue
             info = (C.c_int * 2)(0, -1)
             ctx.check(ctx.lib.oisat_batch_potrf(ctx.h, bid, info if check_pd else None))
+            if self.batched_solve:
+                ctx.check(ctx.lib.oisat_set_refine_tol(ctx.h, REFINE_TOL))
+                ctx.check(ctx.lib.oisat_batch_solve(ctx.h, bid, g[0].code, g[0]._g, int(refine)))
 
         # One enqueueing host thread per group: a polar-cap factorization is ~700 launches = 20-25 ms of host time inside
         # ONE library call, and a single thread enqueued the groups one after the other -- whichever group came second
@@ -379,6 +401,13 @@ class BatchedFactor:
             futures = []
             for gi in range(len(self.groups)):
                 enqueue_group(gi)
+        if self.batched_solve:                              # nothing left for the lanes: wait for the enqueueing threads only
+            for f in futures:
+                f.exception()
+            for f in futures:
+                if f.exception() is not None:
+                    raise f.exception()
+            return
         # release each group's solves as soon as it is factored, in COMPLETION order: poll the group streams
         pending = list(range(len(self.ctxs)))
         while pending:
@@ -394,6 +423,13 @@ class BatchedFactor:
                 pending.remove(gi)
                 pool.enqueue([[(lambda p=p: p.run_solve(refine)) for p in plans if self.group_of[id(p)] == gi]
                               for plans in per_lane_plans])
+
+    def fence(self, pool):
+        """Order every lane behind whatever the group streams still have in flight (the lock-step solves of a previous,
+        unchecked run read the buffers the next run's builds write).  Device-side, and free when the groups are idle."""
+        for lane in pool.lanes:
+            for ctx in self.ctxs:
+                lane.wait_for(ctx)
 
     def check(self, what="batched factorization"):
         errors = []
@@ -641,6 +677,7 @@ class TiledAnalysis:
         if not self.batched:
             self.pool.enqueue(self._per_lane(lambda p: p.run(L_km, refine=refine, check_pd=check_pd)))
             return
+        self.factor.fence(self.pool)
         self.pool.enqueue(self._per_lane(lambda p: p.run_build(L_km)))         # innovation, S = H B H^T + R
         plans = [[] for _ in self.lanes]
         for ti in self._order:
@@ -756,6 +793,7 @@ class MonthTileBatch:
         if not self._run_order:                          # this rank owns no unit with observations
             pass
         elif self.batched:
+            self.factor.fence(self.pool)
             self.pool.enqueue(per_lane(lambda p: p.run_build(L_km)))
             plans = [[] for _ in self.pool.lanes]
             for key, ti in self._run_order:
