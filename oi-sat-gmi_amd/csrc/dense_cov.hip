@@ -287,26 +287,40 @@ extern "C" int oisat_cov_residual(oisat_ctx* h, const double* oxyz, const double
     return oisat_cov_residual_if(h, oxyz, osig, ovar, m, g, d, z, r_out, olat_sorted, nullptr);
 }
 
+// two cells per thread share every observation fetched from LDS; with too few cells to fill the GPU that way (a polar cap:
+// 338 workgroups) one cell per thread doubles the waves in flight instead (OISAT_INC_CELLS = 1 | 2 forces either)
+static inline int increment_cells(const oisat_ctx* h, int64_t n, int nmem) {
+    static const int forced = getenv("OISAT_INC_CELLS") ? atoi(getenv("OISAT_INC_CELLS")) : 0;
+    if (forced == 1 || forced == 2) return forced;
+    const int64_t wgs2 = cdiv(n, 512) * nmem;
+    return wgs2 < 4 * (int64_t)(h->cu_count > 0 ? h->cu_count : 256) ? 1 : 2;
+}
+
+template <typename T, int CELLS, bool BATCH>
+static int increment_launch(oisat_ctx* h, unsigned gy, const double* gxyz, const double* gsig, int64_t n, const double* oxyz,
+                            const double* osig, const double* z, int64_t m, float g2, const void* xb, void* xa, void* inc,
+                            const double* glat, const double* olat, double win, const SolveMember* mem) {
+    const unsigned gx = (unsigned)cdiv(n, 256 * CELLS);
+    OISAT_LAUNCH(h, "apply_increment", (apply_increment_kernel<T, CELLS, BATCH>), dim3(gx, gy), dim3(256), 0, gxyz, gsig, n, oxyz, osig, z,
+                 m, g2, (const T*)xb, (T*)xa, (T*)inc, glat, olat, win, mem);
+    return OISAT_OK;
+}
+
 extern "C" int oisat_apply_increment(oisat_ctx* h, int dtype, const double* gxyz, const double* gsig, int64_t n,
                                      const double* oxyz, const double* osig, const double* z, int64_t m, double g,
                                      const void* xb, void* xa, void* inc, const double* glat, const double* olat_sorted) {
     ARG_CHECK(h && gxyz && gsig && oxyz && osig && z && n > 0 && m > 0 && (xa || inc));
     ARG_CHECK(!xa || xb);
     ARG_CHECK(dtype == OISAT_F32 || dtype == OISAT_F64);
-    constexpr int CELLS = 2;
-    const unsigned grid = (unsigned)cdiv(n, 256 * CELLS);
     const float g2 = (float)(g * (double)kLog2e);
     const double win = lat_window_deg((double)g2);
     if (!(win < 180.0) || !glat || !olat_sorted) { glat = nullptr; olat_sorted = nullptr; }
-    if (dtype == OISAT_F32) {
-        OISAT_LAUNCH(h, "apply_increment", (apply_increment_kernel<float, CELLS, false>), dim3(grid), dim3(256), 0, gxyz, gsig, n, oxyz,
-                     osig, z, m, g2, (const float*)xb, (float*)xa, (float*)inc, glat, olat_sorted, win, (const SolveMember*)nullptr);
-    } else {
-        OISAT_LAUNCH(h, "apply_increment", (apply_increment_kernel<double, CELLS, false>), dim3(grid), dim3(256), 0, gxyz, gsig, n,
-                     oxyz, osig, z, m, g2, (const double*)xb, (double*)xa, (double*)inc, glat, olat_sorted, win,
-                     (const SolveMember*)nullptr);
-    }
-    return OISAT_OK;
+    const int cells = increment_cells(h, n, 1);
+    if (dtype == OISAT_F32)
+        return cells == 1 ? increment_launch<float, 1, false>(h, 1, gxyz, gsig, n, oxyz, osig, z, m, g2, xb, xa, inc, glat, olat_sorted, win, nullptr)
+                          : increment_launch<float, 2, false>(h, 1, gxyz, gsig, n, oxyz, osig, z, m, g2, xb, xa, inc, glat, olat_sorted, win, nullptr);
+    return cells == 1 ? increment_launch<double, 1, false>(h, 1, gxyz, gsig, n, oxyz, osig, z, m, g2, xb, xa, inc, glat, olat_sorted, win, nullptr)
+                      : increment_launch<double, 2, false>(h, 1, gxyz, gsig, n, oxyz, osig, z, m, g2, xb, xa, inc, glat, olat_sorted, win, nullptr);
 }
 
 // ---- batched forms (oisat_batch_solve, dense_chol.hip): blockIdx.y = member of the device table --------------------------
@@ -321,22 +335,15 @@ int oisat_cov_residual_batched(oisat_ctx* h, const SolveMember* mem_dev, int nme
 }
 
 int oisat_apply_increment_batched(oisat_ctx* h, int dtype, const SolveMember* mem_dev, int nmem, int64_t max_n, double g) {
-    constexpr int CELLS = 2;
-    const unsigned gx = (unsigned)cdiv(max_n, 256 * CELLS);
     const float g2 = (float)(g * (double)kLog2e);
     const double win = lat_window_deg((double)g2);
     static const double dummy = 0.0;
     const double* use = win < 180.0 ? &dummy : (const double*)nullptr;
-    if (dtype == OISAT_F32) {
-        OISAT_LAUNCH(h, "apply_increment", (apply_increment_kernel<float, CELLS, true>), dim3(gx, (unsigned)nmem), dim3(256), 0,
-                     (const double*)nullptr, (const double*)nullptr, (int64_t)0, (const double*)nullptr, (const double*)nullptr,
-                     (const double*)nullptr, (int64_t)0, g2, (const float*)nullptr, (float*)nullptr, (float*)nullptr, use, use, win,
-                     mem_dev);
-    } else {
-        OISAT_LAUNCH(h, "apply_increment", (apply_increment_kernel<double, CELLS, true>), dim3(gx, (unsigned)nmem), dim3(256), 0,
-                     (const double*)nullptr, (const double*)nullptr, (int64_t)0, (const double*)nullptr, (const double*)nullptr,
-                     (const double*)nullptr, (int64_t)0, g2, (const double*)nullptr, (double*)nullptr, (double*)nullptr, use, use,
-                     win, mem_dev);
-    }
-    return OISAT_OK;
+    const int cells = increment_cells(h, max_n, nmem);
+    const unsigned gy = (unsigned)nmem;
+    if (dtype == OISAT_F32)
+        return cells == 1 ? increment_launch<float, 1, true>(h, gy, nullptr, nullptr, max_n, nullptr, nullptr, nullptr, 0, g2, nullptr, nullptr, nullptr, use, use, win, mem_dev)
+                          : increment_launch<float, 2, true>(h, gy, nullptr, nullptr, max_n, nullptr, nullptr, nullptr, 0, g2, nullptr, nullptr, nullptr, use, use, win, mem_dev);
+    return cells == 1 ? increment_launch<double, 1, true>(h, gy, nullptr, nullptr, max_n, nullptr, nullptr, nullptr, 0, g2, nullptr, nullptr, nullptr, use, use, win, mem_dev)
+                      : increment_launch<double, 2, true>(h, gy, nullptr, nullptr, max_n, nullptr, nullptr, nullptr, 0, g2, nullptr, nullptr, nullptr, use, use, win, mem_dev);
 }

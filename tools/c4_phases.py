@@ -33,6 +33,21 @@ for rep in range(2):
     for g, bid in zip(f.ctxs, f.ids):
         g.check(g.lib.oisat_batch_potrf(g.h, bid, None))
     sync_all(); t2 = time.perf_counter()
-    batch.pool.enqueue(per_lane(lambda p: p.run_solve(2))); sync_all(); t3 = time.perf_counter()
+    if f.batched_solve:                                  # lock-step solves, one group after the other (each alone)
+        per_group = []
+        for g, bid, members in zip(f.ctxs, f.ids, f.groups):
+            prof_on = rep == 1 and os.environ.get("PROF", "0") == "1"
+            if prof_on:
+                g.prof_reset(); g.prof_enable(True)
+            ta = time.perf_counter()
+            g.check(g.lib.oisat_batch_solve(g.h, bid, members[0].code, members[0]._g, 2)); g.sync()
+            per_group.append(1e3 * (time.perf_counter() - ta))
+            if prof_on:
+                pr = g.prof_collect(); g.prof_enable(False)
+                print("   group of %d:" % len(members), {k: (v["launches"], round(v["total_ms"], 2)) for k, v in pr.items()})
+        print("   lock-step solves per group (alone):", ["%.1f ms" % x for x in per_group])
+    else:
+        batch.pool.enqueue(per_lane(lambda p: p.run_solve(2)))
+    sync_all(); t3 = time.perf_counter()
     print("months %d: build %.1f ms | factor (groups side by side) %.1f ms | solves %.1f ms | total %.1f ms" % (NM, 1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (t3 - t2), 1e3 * (t3 - t0)))
 t0 = time.perf_counter(); batch.run(L, refine=2); print("run() %.1f ms" % (1e3 * (time.perf_counter() - t0)))
