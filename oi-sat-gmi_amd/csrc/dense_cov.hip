@@ -145,6 +145,23 @@ __global__ __launch_bounds__(256) void cov_residual_kernel(const double* __restr
     }
 }
 
+// 2^x for x <= 0 in double to 2e-10 relative: x = n + f, |f| <= 1/2, 2^f = e^(f ln 2) by a degree-8 polynomial, 2^n by ldexp
+__device__ __forceinline__ double exp2_neg(double x) {
+    x = fmax(x, -1100.0);                                                   // (far pairs outside any window: 2^x = 0)
+    const double n = __builtin_rint(x);
+    const double t = (x - n) * 0.6931471805599453;                          // |t| <= 0.3466
+    double p = 2.48015873015873e-05;                                        // 1/8!
+    p = __builtin_fma(p, t, 1.984126984126984e-04);
+    p = __builtin_fma(p, t, 1.388888888888889e-03);
+    p = __builtin_fma(p, t, 8.333333333333333e-03);
+    p = __builtin_fma(p, t, 4.1666666666666664e-02);
+    p = __builtin_fma(p, t, 1.6666666666666666e-01);
+    p = __builtin_fma(p, t, 0.5);
+    p = __builtin_fma(p, t, 1.0);
+    p = __builtin_fma(p, t, 1.0);
+    return __builtin_ldexp(p, (int)n);
+}
+
 // ---- inc_i = sig_i * sum_a C(i,a) w_a, w = osig.*z ; xa = xb + inc --------------------------------------------
 // Thread = CELLS grid cells, block = 256 threads; observations stream through LDS in chunks and
 // are read as wave-uniform (broadcast) 16-byte words.  |p-q|^2 is formed in double: with float
@@ -158,7 +175,7 @@ template <typename T, int CELLS, bool BATCH>
 __global__ __launch_bounds__(256) void apply_increment_kernel(const double* __restrict__ gxyz, const double* __restrict__ gsig,
                                                                int64_t n, const double* __restrict__ oxyz,
                                                                const double* __restrict__ osig, const double* __restrict__ z,
-                                                               int64_t m, float g2,
+                                                               int64_t m, double g2,
                                                                const T* __restrict__ xb, T* __restrict__ xa, T* __restrict__ inc,
                                                                const double* __restrict__ glat, const double* __restrict__ olat,
                                                                double win_deg, const SolveMember* __restrict__ mem) {
@@ -230,8 +247,12 @@ __global__ __launch_bounds__(256) void apply_increment_kernel(const double* __re
 #pragma unroll
             for (int q = 0; q < CELLS; ++q) {
                 const double dx = px[q] - oxy.x, dy = py[q] - oxy.y, dz = pz[q] - ozw.x;
-                const float d2 = (float)(dx * dx + dy * dy + dz * dz);
-                acc[q] += (double)__builtin_amdgcn_exp2f(-g2 * d2) * ozw.y;
+                // C = 2^x, x = -g2 |p - q|^2, in DOUBLE (exp2_neg, 2e-10).  Rounds 1-2 used v_exp_f32: good to 1 ulp = 1.2e-7 of the
+                // term, but the terms cancel (sum|term| is several hundred times the field at swath densities, more at larger L)
+                // and that alone put the fields 2.5e-6 of their scale off at 720x1440 / 1e5 obs, L = 300 km, and 1.3e-5 -- outside
+                // the 1e-5 bar -- at 360x720 / 1e4 gridded obs, L = 500 km; with this: 4e-8.  Costs twice the kernel time
+                // (taking only the pairs with C > 2^-8 in double diverges inside the waves and is slower still at L = 500 km).
+                acc[q] += exp2_neg(-g2 * (dx * dx + dy * dy + dz * dz)) * ozw.y;
             }
         }
     }
@@ -298,7 +319,7 @@ static inline int increment_cells(const oisat_ctx* h, int64_t n, int nmem) {
 
 template <typename T, int CELLS, bool BATCH>
 static int increment_launch(oisat_ctx* h, unsigned gy, const double* gxyz, const double* gsig, int64_t n, const double* oxyz,
-                            const double* osig, const double* z, int64_t m, float g2, const void* xb, void* xa, void* inc,
+                            const double* osig, const double* z, int64_t m, double g2, const void* xb, void* xa, void* inc,
                             const double* glat, const double* olat, double win, const SolveMember* mem) {
     const unsigned gx = (unsigned)cdiv(n, 256 * CELLS);
     OISAT_LAUNCH(h, "apply_increment", (apply_increment_kernel<T, CELLS, BATCH>), dim3(gx, gy), dim3(256), 0, gxyz, gsig, n, oxyz, osig, z,
@@ -312,8 +333,8 @@ extern "C" int oisat_apply_increment(oisat_ctx* h, int dtype, const double* gxyz
     ARG_CHECK(h && gxyz && gsig && oxyz && osig && z && n > 0 && m > 0 && (xa || inc));
     ARG_CHECK(!xa || xb);
     ARG_CHECK(dtype == OISAT_F32 || dtype == OISAT_F64);
-    const float g2 = (float)(g * (double)kLog2e);
-    const double win = lat_window_deg((double)g2);
+    const double g2 = g * (double)kLog2e;
+    const double win = lat_window_deg(g2);
     if (!(win < 180.0) || !glat || !olat_sorted) { glat = nullptr; olat_sorted = nullptr; }
     const int cells = increment_cells(h, n, 1);
     if (dtype == OISAT_F32)
@@ -335,8 +356,8 @@ int oisat_cov_residual_batched(oisat_ctx* h, const SolveMember* mem_dev, int nme
 }
 
 int oisat_apply_increment_batched(oisat_ctx* h, int dtype, const SolveMember* mem_dev, int nmem, int64_t max_n, double g) {
-    const float g2 = (float)(g * (double)kLog2e);
-    const double win = lat_window_deg((double)g2);
+    const double g2 = g * (double)kLog2e;
+    const double win = lat_window_deg(g2);
     static const double dummy = 0.0;
     const double* use = win < 180.0 ? &dummy : (const double*)nullptr;
     const int cells = increment_cells(h, max_n, nmem);

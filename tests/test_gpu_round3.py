@@ -296,3 +296,39 @@ def test_batched_factorization_with_leaf_pairs(ctx):
             ctx.check(lib.oisat_batch_potrf(ctx.h, bid.value, info2))
         ctx.solve_status(clear=True)
         ctx.check(lib.oisat_batch_destroy(ctx.h, bid.value))
+
+
+def test_oi_dense_mode_through_the_facade_at_config2_size(ctx):
+    """oisatgmi.oi(sensor, error_ctm) in `dense` mode at 360x720 with 1e4 observed cells -- the four
+    attributes of driver.py:110-114, posterior error and averaging kernel included, against oracle.dense_oi on a subsample
+    of the grid (every observed cell + 3000 others): analysis and increment 1e-6 of the field scale, error 2e-3, AK 5e-4."""
+    from oisatgmi.driver import oisatgmi
+    c = syn.diag_case(360, 720, 10000, 2001)
+    lat, lon = syn.global_grid(360, 720)
+    o = oisatgmi()
+    o.ctm_averaged_vcd, o.sat_averaged_vcd = c.Xa.copy(), c.Y.copy()
+    o.sat_averaged_error = np.sqrt(c.So)
+    o.grid_lat, o.grid_lon = lat, lon
+    o.oi_mode, o.corr_length_km, o.oi_unobserved = "dense", 500.0, "xa"
+    o.oi("OMI", error_ctm=50.0)
+    s = o.oi_info["scale"]
+    assert o.oi_info["mode"] == "dense" and o.oi_info["want_error"] and o.oi_info["nobs"] > 9000
+    Y = np.where(c.Y < 0, 0.0, c.Y)
+    obs = np.isfinite(Y) & np.isfinite(c.So)
+    cell = np.flatnonzero(obs.ravel())
+    rng = np.random.default_rng(11)
+    others = rng.choice(np.flatnonzero(~obs.ravel()), 3000, replace=False)
+    sub = np.concatenate([cell, others])                        # the oracle's "grid": the observed cells first
+    ref = orc.dense_oi(lat.ravel()[sub], lon.ravel()[sub], c.Xa.ravel()[sub], (0.5 * c.Xa.ravel()[sub]) ** 2,
+                       lat.ravel()[cell], lon.ravel()[cell], np.arange(cell.size), Y.ravel()[cell], c.So.ravel()[cell], 500.0,
+                       scale=s, want_error=True)
+    fs = np.abs(c.Xa).max()
+    # 1e-6, not 1e-5: with the increment's exponentials in double the fields sit at 4e-8 of the scale here (L = 500 km, gridded
+    # observations: the case where rounds 1-2's v_exp_f32 left them 1.3e-5 off)
+    assert np.abs(o.ctm_averaged_vcd_corrected.ravel()[sub] - ref["xa"]).max() <= 1e-6 * fs
+    assert np.abs(o.increment_OI.ravel()[sub] - ref["inc"]).max() <= 1e-6 * fs
+    np.testing.assert_allclose(o.error_OI.ravel()[sub], ref["err"], rtol=2e-3, atol=1e-4 * fs)
+    np.testing.assert_allclose(o.ak_OI.ravel()[cell], ref["ak_obs"], rtol=0, atol=5e-4)   # diag(K H) from the fp32 factor alone
+    assert (o.ak_OI.ravel()[others] == 0).all()                  # unobserved cells: averaging kernel 0 (OISAT_UNOBSERVED=xa)
+    for a in (o.ctm_averaged_vcd_corrected, o.ak_OI, o.increment_OI, o.error_OI):
+        assert a.shape == (360, 720) and np.isfinite(a).all()
