@@ -1030,12 +1030,12 @@ __device__ __forceinline__ void diag16_pivots(float (&d)[16], float (&x)[16], in
     }
 }
 
-__device__ __forceinline__ void diag16_report(int bad, int* info, int col0, int lane) {
+__device__ __forceinline__ void diag16_report(int bad, int* info, int col0, int lane, int which) {
     if (bad && lane == 0) {               // info[0]: this factorization; info[1], info[2]: sticky (first column, count)
         atomicCAS(info, 0, col0 + bad);  //          until oisat_solve_status clears them
         atomicCAS(info + 1, 0, col0 + bad);
         atomicAdd(info + 2, 1);
-        atomicCAS(info + 3, 0, (int)blockIdx.x + 1);   // batched factorization: which matrix of the table (1-based)
+        atomicCAS(info + 3, 0, which + 1);             // batched factorization: which matrix of the table (1-based)
     }
 }
 
@@ -1099,6 +1099,44 @@ __device__ __forceinline__ f32x4 d3_mma_regb(const float* a, f32x4 breg, int lr,
 // so waiting for their acknowledgement (1-2 us each time) is pure loss.
 __device__ __forceinline__ void d3_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Global stores of the diagonal-block kernel: (wave-uniform base, per-lane element offset).  WT (the task-graph factorization,
+// where OTHER workgroups of the same launch read L and T): write-through `sc1` stores -- the bytes leave the XCD's L2 at once,
+// so publishing them takes a drained vmcnt and a flag instead of an L2 write-back (buffer_wbl2) per diagonal block.  Buffer
+// stores, not inline assembly: the stored values come straight out of MFMA instructions, and the wait states between an MFMA
+// and a memory instruction that reads its result are the compiler's to insert -- it does not look into asm blocks (a
+// global_store in inline assembly stored the register's OLD content: one wrong element per tile, found the hard way).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t d3_rsrc(const gfloat* base) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, (short)0, 0x7ffffff0, 0x00020000);
+}
+template <bool WT>
+__device__ __forceinline__ void d3_gst(gfloat* base, int64_t off, float v) {
+    if (WT) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), d3_rsrc(base), (int)(off * 4), 0, 16);
+    else base[off] = v;
+}
+template <bool WT>
+__device__ __forceinline__ void d3_gst4(gfloat* base, int64_t off, f32x4 v) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    if (WT) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), d3_rsrc(base), (int)(off * 4), 0, 16);
+    else *reinterpret_cast<gf32x4*>(base + off) = v;
+}
+
+// Loads of the block's tiles.  WT: `sc1` buffer loads (served by L2, never by this CU's L1, which may hold the tile as it was
+// before another workgroup -- or this one's write-through stores -- updated it).
+template <bool WT>
+__device__ __forceinline__ float d3_gld(const gfloat* Sb, int64_t ld, int row, int col) {
+    if (WT) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(d3_rsrc(Sb), (int)((row * ld + col) * 4), 0, 16));
+    }
+    return Sb[(int64_t)row * ld + col];
+}
+template <bool WT>
+__device__ __forceinline__ f32x4 d3_gld4(const gfloat* Sb, int64_t ld, int row, int col) {
+    if (WT) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(d3_rsrc(Sb), (int)((row * ld + col) * 4), 0, 16));
+    }
+    return *reinterpret_cast<const gf32x4*>(Sb + (int64_t)row * ld + col);
+}
+
 __device__ __forceinline__ void d3_put(float* tile, f32x4 acc, int lr, int lg) {   // accumulator layout -> row-major tile
 #pragma unroll
     for (int e = 0; e < 4; ++e) tile[(4 * lg + e) * D3_LD + lr] = acc[e];
@@ -1107,7 +1145,7 @@ __device__ __forceinline__ void d3_put(float* tile, f32x4 acc, int lr, int lg) {
 // factor + invert the diagonal tile held in `acc` (by the calling wave): L16 (full rows, the upper part is garbage) to
 // `stage`, X16 = L16^-1 to `dinv`; a worker wave copies both to global memory in the next panel phase
 constexpr int D3_SLD = 20;                 // row stride of the staging tile: 16-byte aligned rows (ds_read_b128 / ds_write_b128)
-__device__ __forceinline__ void d3_diag16(f32x4 acc, float* stage, float* dinv, int* info, int col0, int lane, int lr, int lg) {
+__device__ __forceinline__ void d3_diag16(f32x4 acc, float* stage, float* dinv, int* info, int col0, int lane, int lr, int lg, int which) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) stage[(4 * lg + e) * D3_SLD + lr] = acc[e];
     __builtin_amdgcn_wave_barrier();
@@ -1122,7 +1160,7 @@ __device__ __forceinline__ void d3_diag16(f32x4 acc, float* stage, float* dinv, 
     for (int c = 0; c < 16; ++c) x[c] = (c == lr) ? 1.f : 0.f;
     int bad = 0;
     diag16_pivots<0>(d, x, lr, bad);
-    diag16_report(bad, info, col0, lane);
+    diag16_report(bad, info, col0, lane, which);
     __builtin_amdgcn_wave_barrier();
     if (lane < 16) {                       // (the other three 16-lane rows hold copies)
 #pragma unroll
@@ -1134,26 +1172,28 @@ __device__ __forceinline__ void d3_diag16(f32x4 acc, float* stage, float* dinv, 
 }
 
 // a worker copies the freshly factored diagonal tile J to global memory: L16 (lower part) and T's diagonal tile
+template <bool WT>
 __device__ __forceinline__ void d3_store_diag(gfloat* Sjj, int64_t ld, gfloat* Tjj, const float* stage, const float* dinv, int lr, int lg) {
     const f32x4 l = *reinterpret_cast<const f32x4*>(stage + lr * D3_SLD + 4 * lg);
     f32x4 t;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         t[e] = dinv[lr * D3_LD + 4 * lg + e];
-        if (4 * lg + e <= lr) Sjj[(int64_t)lr * ld + 4 * lg + e] = l[e];
+        if (4 * lg + e <= lr) d3_gst<WT>(Sjj, (int64_t)lr * ld + 4 * lg + e, l[e]);
     }
-    *reinterpret_cast<gf32x4*>(Tjj + lr * NB + 4 * lg) = t;
+    d3_gst4<WT>(Tjj, lr * NB + 4 * lg, t);
 }
 
 // wave 0: the diagonal tiles
+template <bool WT>
 __device__ __forceinline__ void d3_diagonal_wave(gfloat* Sb, int64_t ld, const float* Pp, float* dinvb, float* stage, int* info,
-                                                 int col0, int lane, int lr, int lg) {
+                                                 int col0, int lane, int lr, int lg, int which) {
     f32x4 accD[8];
 #pragma unroll
     for (int J = 0; J < 8; ++J)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) accD[J][e] = Sb[(int64_t)(16 * J + 4 * lg + e) * ld + 16 * J + lr];
-    d3_diag16(accD[0], stage, dinvb, info, col0, lane, lr, lg);
+        for (int e = 0; e < 4; ++e) accD[J][e] = d3_gld<WT>(Sb, ld, 16 * J + 4 * lg + e, 16 * J + lr);
+    d3_diag16(accD[0], stage, dinvb, info, col0, lane, lr, lg, which);
 #pragma unroll
     for (int J = 0; J < 8; ++J) {
         d3_barrier();                      // Dinv_J is in LDS; every wave is done with step J-1
@@ -1167,12 +1207,12 @@ __device__ __forceinline__ void d3_diagonal_wave(gfloat* Sb, int64_t ld, const f
         // look-ahead: tile (J+1, J+1) takes panel J's update and is factored at once (its older updates are in already)
         const float* pj = Pp + (J & 1) * D3_PBUF + J * D3_TILE;
         accD[J + 1] = d3_mma<true, true>(accD[J + 1], pj, pj, lr, lg);
-        d3_diag16(accD[J + 1], stage, dinvb + ((J + 1) & 1) * D3_TILE, info, col0 + 16 * (J + 1), lane, lr, lg);
+        d3_diag16(accD[J + 1], stage, dinvb + ((J + 1) & 1) * D3_TILE, info, col0 + 16 * (J + 1), lane, lr, lg, which);
     }
 }
 
 // waves 1..3: the off-diagonal tiles idx = 3 t + W - 1
-template <int W>
+template <int W, bool WT>
 __device__ __forceinline__ void d3_worker_wave(gfloat* Sb, int64_t ld, gfloat* Tg, float* Pp, float* Xr, const float* dinvb, const float* stage,
                                                int lr, int lg) {
     constexpr int NS = (28 - (W - 1) + 2) / 3;
@@ -1180,8 +1220,8 @@ __device__ __forceinline__ void d3_worker_wave(gfloat* Sb, int64_t ld, gfloat* T
 #pragma unroll
     for (int t = 0; t < NS; ++t) {
         const int I = d3_I(3 * t + W - 1), K = d3_K(3 * t + W - 1);
-        acc[t] = *reinterpret_cast<const gf32x4*>(Sb + (int64_t)(16 * I + lr) * ld + 16 * K + 4 * lg);            // A[I,K]^T
-        *reinterpret_cast<gf32x4*>(Tg + (16 * K + lr) * NB + 16 * I + 4 * lg) = f32x4{0.f, 0.f, 0.f, 0.f};        // T is lower triangular
+        acc[t] = d3_gld4<WT>(Sb, ld, 16 * I + lr, 16 * K + 4 * lg);                                             // A[I,K]^T
+        d3_gst4<WT>(Tg, (16 * K + lr) * NB + 16 * I + 4 * lg, f32x4{0.f, 0.f, 0.f, 0.f});                         // T is lower triangular
     }
 #pragma unroll
     for (int J = 0; J < 8; ++J) {
@@ -1189,7 +1229,7 @@ __device__ __forceinline__ void d3_worker_wave(gfloat* Sb, int64_t ld, gfloat* T
         float* P = Pp + (J & 1) * D3_PBUF;                 // panel J: tile I (>= 1) at P + (I - 1) * D3_TILE; two buffers, by parity of J
         d3_barrier();                      // Dinv_J is in LDS; every wave is done with step J-1 (P, Xr may be rewritten)
         if (J % 3 == W - 1)                // the diagonal tile wave 0 has just factored: to global memory
-            d3_store_diag(Sb + (int64_t)16 * J * ld + 16 * J, ld, Tg + 16 * J * NB + 16 * J, stage, dinv, lr, lg);
+            d3_store_diag<WT>(Sb + (int64_t)16 * J * ld + 16 * J, ld, Tg + 16 * J * NB + 16 * J, stage, dinv, lr, lg);
 #pragma unroll
         for (int t = 0; t < NS; ++t) {
             const int I = d3_I(3 * t + W - 1), K = d3_K(3 * t + W - 1);
@@ -1197,13 +1237,13 @@ __device__ __forceinline__ void d3_worker_wave(gfloat* Sb, int64_t ld, gfloat* T
                 const f32x4 pt = d3_mma_regb(dinv, acc[t], lr, lg);             // lane: P_I[lr][4 lg + e]
 #pragma unroll
                 for (int e = 0; e < 4; ++e) P[(I - 1) * D3_TILE + lr * D3_LD + 4 * lg + e] = pt[e];
-                *reinterpret_cast<gf32x4*>(Sb + (int64_t)(16 * I + lr) * ld + 16 * J + 4 * lg) = pt;
+                d3_gst4<WT>(Sb, (int64_t)(16 * I + lr) * ld + 16 * J + 4 * lg, pt);
                 acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
             } else if (I == J) {           // row J of the inverse (K < J): X[J,K] = Dinv_J * acc
                 const f32x4 xf = d3_mma_regb(dinv, acc[t], lr, lg);
                 d3_put(Xr + K * D3_TILE, xf, lr, lg);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) Tg[(16 * J + 4 * lg + e) * NB + 16 * K + lr] = xf[e];
+                for (int e = 0; e < 4; ++e) d3_gst<WT>(Tg, (16 * J + 4 * lg + e) * NB + 16 * K + lr, xf[e]);
             }
         }
         d3_barrier();                      // the panel and row J of X are in LDS
@@ -1236,10 +1276,10 @@ __global__ __launch_bounds__(D3_THREADS, 4) void potrf_diag3_kernel(float* __res
     const int lr = lane & 15, lg = lane >> 4;
     gfloat* Sb = (gfloat*)(S + k0 * ld + k0);
     gfloat* Tg = (gfloat*)(tinv + (int64_t)block_index * NB * NB);
-    if (w == 0) d3_diagonal_wave(Sb, ld, Pp, dinvb, stage, info, (int)k0, lane, lr, lg);
-    else if (w == 1) d3_worker_wave<1>(Sb, ld, Tg, Pp, Xr, dinvb, stage, lr, lg);
-    else if (w == 2) d3_worker_wave<2>(Sb, ld, Tg, Pp, Xr, dinvb, stage, lr, lg);
-    else d3_worker_wave<3>(Sb, ld, Tg, Pp, Xr, dinvb, stage, lr, lg);
+    if (w == 0) d3_diagonal_wave<false>(Sb, ld, Pp, dinvb, stage, info, (int)k0, lane, lr, lg, (int)blockIdx.x);
+    else if (w == 1) d3_worker_wave<1, false>(Sb, ld, Tg, Pp, Xr, dinvb, stage, lr, lg);
+    else if (w == 2) d3_worker_wave<2, false>(Sb, ld, Tg, Pp, Xr, dinvb, stage, lr, lg);
+    else d3_worker_wave<3, false>(Sb, ld, Tg, Pp, Xr, dinvb, stage, lr, lg);
 }
 
 // identity padding of rows m..mp (columns 0..mp)
@@ -2096,7 +2136,25 @@ hipError_t dense_kernel_attributes() {
     return attr_rc;
 }
 
+#include "dense_dag.inc"
+
+// Which factorizations run as a task graph: systems of OISAT_DAG_MIN_BLOCKS .. OISAT_DAG_MAX_BLOCKS block rows (a single
+// system) / batches whose largest member has at most OISAT_DAG_MAX_BLOCKS; OISAT_DAG=0 turns it off, OISAT_DAG=1 forces it.
+// Above the upper bound the recursion's K >= 2048 GEMMs (8x8 tile patches per XCD, 0.88 of the MFMA peak) win.
+// (read at every call: a plan is made once per system / batch, and tests switch the schedule inside one process)
+static inline bool dag_wanted(int64_t max_blocks, int nsys, int cu_count) {
+    const int kDagMode = getenv("OISAT_DAG") ? atoi(getenv("OISAT_DAG")) : -1;
+    const int kDagMinBlocks = getenv("OISAT_DAG_MIN_BLOCKS") ? atoi(getenv("OISAT_DAG_MIN_BLOCKS")) : 3;
+    const int kDagMaxBlocks = getenv("OISAT_DAG_MAX_BLOCKS") ? atoi(getenv("OISAT_DAG_MAX_BLOCKS")) : 200;
+    if (kDagMode == 0) return false;
+    if (nsys > (cu_count > 0 ? cu_count : 256) / 2) return false;      // every chain needs a running workgroup of its own
+    if (kDagMode == 1) return max_blocks >= 2;
+    return max_blocks >= kDagMinBlocks && max_blocks <= kDagMaxBlocks;
+}
+
 }  // namespace
+
+void oisat_dag_plan_release(void* plan) { dag_plan_free((DagPlan*)plan); }
 
 extern "C" int oisat_set_refine_tol(oisat_ctx* h, double tol) {
     ARG_CHECK(h != nullptr && tol >= 0.0 && tol < 1.0);
@@ -2149,7 +2207,37 @@ extern "C" int oisat_potrf(oisat_ctx* h, float* S, int64_t m, int64_t ld, int* i
             if (env[9] == ':' && atoi(env + 10) > 0) pw = atoi(env + 10);      // OISAT_POTRF=lookahead:4
         }
     }
-    const int rc = lookahead ? potrf_lookahead(h, S, ld, mpb, tinv, info_dev, pw) : potrf_rec(h, S, ld, mpb, 0, mpb, tinv, info_dev);
+    int rc;
+    if (!lookahead && !getenv("OISAT_POTRF") && dag_wanted(mpb, 1, h->cu_count)) {
+        // the plan of this (S, tinv, ld, block rows) -- a handle keeps the last few (a lane that factors its tiles one after
+        // the other in ONE shared buffer meets the same few sizes month after month)
+        DagSingle* hit = nullptr;
+        for (DagSingle& c : h->dag_cache)
+            if (c.plan && c.S == S && c.tinv == tinv && c.ld == ld && c.mpb == mpb) hit = &c;
+        if (!hit) {
+            DagSingle* slot = nullptr;
+            for (DagSingle& c : h->dag_cache)
+                if (!c.plan) { slot = &c; break; }
+            if (!slot) {                                         // evict the least recently used
+                slot = &h->dag_cache[0];
+                for (DagSingle& c : h->dag_cache)
+                    if (c.stamp < slot->stamp) slot = &c;
+                HIP_TRY(hipStreamSynchronize(h->stream));        // (a plan is never freed under a running launch)
+                oisat_dag_plan_release(slot->plan);
+                slot->plan = nullptr;
+            }
+            slot->plan = dag_plan_create(std::vector<BatchMat>{BatchMat{S, tinv, ld, m, (int)mpb, 0}}, h->stream);
+            if (!slot->plan) return OISAT_ENOMEM;
+            slot->S = S; slot->tinv = tinv; slot->ld = ld; slot->mpb = mpb;
+            hit = slot;
+        }
+        hit->stamp = ++h->dag_clock;
+        char* tbase = nullptr;
+        if (int rs = status_ws(h, nullptr, &tbase)) return rs;
+        rc = dag_launch(h, *(DagPlan*)hit->plan, info_dev, (unsigned*)tbase);
+    } else {
+        rc = lookahead ? potrf_lookahead(h, S, ld, mpb, tinv, info_dev, pw) : potrf_rec(h, S, ld, mpb, 0, mpb, tinv, info_dev);
+    }
     if (rc) return rc;
     h->factor.S = S;
     h->factor.m = m;
@@ -2386,6 +2474,15 @@ extern "C" int oisat_batch_create(oisat_ctx* h, int nmat, float* const* S, const
             return OISAT_ENOMEM;
         }
     }
+    if (dag_wanted(bt->max_mpb, nmat, h->cu_count)) {
+        bt->dag = dag_plan_create(bt->table, h->stream);
+        if (!bt->dag) {
+            (void)hipFree(bt->cum_dev);
+            (void)hipFree(bt->table_dev);
+            delete bt;
+            return OISAT_ENOMEM;
+        }
+    }
     int id = -1;
     for (size_t i = 0; i < h->batches.size(); ++i)
         if (!h->batches[i]) { id = (int)i; break; }
@@ -2404,6 +2501,7 @@ extern "C" int oisat_batch_destroy(oisat_ctx* h, int batch_id) {
     if (bt->solve_dev) HIP_TRY(hipFree(bt->solve_dev));
     if (bt->ord_dev) HIP_TRY(hipFree(bt->ord_dev));
     if (bt->ctl_dev) HIP_TRY(hipFree(bt->ctl_dev));
+    oisat_dag_plan_release(bt->dag);
     delete bt;
     h->batches[batch_id] = nullptr;
     return OISAT_OK;
@@ -2507,7 +2605,14 @@ extern "C" int oisat_batch_potrf(oisat_ctx* h, int batch_id, int* info_host) {
     HIP_TRY(hipMemsetAsync(info_dev + 3, 0, sizeof(int), h->stream));
     OISAT_LAUNCH(h, "pad_identity", pad_identity_batched_kernel, dim3(32, (unsigned)bt.table.size()), dim3(256), 0,
                  (const BatchMat*)bt.table_dev);
-    const int rc = potrf_rec_batched(h, bt, 0, bt.max_mpb, info_dev);
+    int rc;
+    if (bt.dag) {
+        char* tbase = nullptr;
+        if (int rs = status_ws(h, nullptr, &tbase)) return rs;
+        rc = dag_launch(h, *(DagPlan*)bt.dag, info_dev, (unsigned*)tbase);
+    } else {
+        rc = potrf_rec_batched(h, bt, 0, bt.max_mpb, info_dev);
+    }
     if (rc) return rc;
     if (info_host) {
         int* pin = (int*)oisat_pinned(h, 64);

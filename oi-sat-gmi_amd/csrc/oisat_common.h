@@ -85,6 +85,15 @@ struct ChBatch {                 // matrices factored in lock-step by oisat_batc
     int ord_total = 0;
     int64_t max_m = 0, max_n = 0, max_mp = 0;
     bool pairs = false;          // leaves of its recursion are pairs of block columns (many members: the leaf launches are HBM-bound)
+    void* dag = nullptr;         // task-graph plan of the batch (dense_dag.inc: DagPlan), owned
+};
+
+struct DagSingle {               // a cached single-system task-graph plan (oisat_potrf)
+    void* plan = nullptr;
+    const float* S = nullptr;
+    const float* tinv = nullptr;
+    int64_t ld = 0, mpb = 0;
+    uint64_t stamp = 0;
 };
 
 struct oisat_ctx {
@@ -118,6 +127,9 @@ struct oisat_ctx {
     int comm_rank = 0, comm_size = 1;
     hipEvent_t signal_event = nullptr;  // oisat_wait_for: recorded on this handle's stream, waited on by another handle's
     std::vector<ChBatch*> batches;      // oisat_batch_create
+    // task-graph plans of the last single-system factorizations on this handle (dense_dag.inc), keyed by what a plan depends on
+    DagSingle dag_cache[8];
+    uint64_t dag_clock = 0;
     // pinned host scratch for small synchronous read-backs
     void* pinned = nullptr;
     size_t pinned_bytes = 0;
@@ -143,6 +155,7 @@ struct oisat_ctx {
 // workspace slot `slot` of at least `bytes` (grow-only); returns nullptr + error on failure
 void* oisat_ws(oisat_ctx* h, int slot, size_t bytes);
 void* oisat_pinned(oisat_ctx* h, size_t bytes);
+void oisat_dag_plan_release(void* plan);                // dense_chol.hip: frees a task-graph plan (nullptr allowed)
 
 int oisat_prof_begin(oisat_ctx* h, const char* name);   // returns pending index or -1
 void oisat_prof_end(oisat_ctx* h, int pending);

@@ -65,8 +65,10 @@ extern "C" void oisat_shutdown(oisat_ctx* h) {
             if (b->solve_dev) (void)hipFree(b->solve_dev);
             if (b->ord_dev) (void)hipFree(b->ord_dev);
             if (b->ctl_dev) (void)hipFree(b->ctl_dev);
+            oisat_dag_plan_release(b->dag);
             delete b;
         }
+    for (DagSingle& c : h->dag_cache) oisat_dag_plan_release(c.plan);
     delete h;
 }
 

@@ -304,6 +304,17 @@ class BatchedFactor:
     def __init__(self, device: int, plans, ratio: float = 0.5):
         groups = []
         order = sorted((p for p in plans if p is not None), key=lambda p: -p.m)
+        # Task-graph factorization (csrc/dense_dag.inc; OISAT_DAG=0 turns it off): ONE persistent launch factors systems of
+        # any mix of sizes -- tiles and polar caps together, every system's chain on a workgroup of its own, the tile tasks of
+        # all systems drawn from one list -- so the groups are simply runs of at most OISAT_DAG_GROUP systems (default 96;
+        # the library takes up to half the CU count) in order of size.  Without it: lock-step recursion, which wants groups
+        # of comparable block count.
+        self.dag = (os.environ.get("OISAT_DAG", "-1") != "0" and bool(order)
+                    and order[0].mp // NB <= int(os.environ.get("OISAT_DAG_MAX_BLOCKS", "200")))
+        if self.dag:
+            per = max(1, int(os.environ.get("OISAT_DAG_GROUP", "96")))
+            groups = [order[i:i + per] for i in range(0, len(order), per)]
+            order = []
         cur = []
         for p in order:
             if cur and p.mp < ratio * cur[0].mp:
