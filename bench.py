@@ -123,22 +123,29 @@ def roofline_leg(ctx, plan, L, refine, psteps):
     prof = ctx.prof_collect()
     ctx.prof_enable(False)
     m = plan.m
-    gemm_ms = sum(prof[k]["total_ms"] for k in ("syrk_gemm", "trsm_gemm") if k in prof) / psteps
-    gemm_launches = sum(prof[k]["launches"] for k in ("syrk_gemm", "trsm_gemm") if k in prof) / psteps
+    # the factorization's kernels: ONE potrf_dag launch (task graph: tile GEMMs, diagonal blocks and panels inside it), or --
+    # OISAT_DAG=0 -- the recursion's GEMM launches (diagonal blocks apart)
+    dag = "potrf_dag" in prof
+    names = ("potrf_dag",) if dag else ("syrk_gemm", "trsm_gemm")
+    gemm_ms = sum(prof[k]["total_ms"] for k in names if k in prof) / psteps
+    gemm_launches = sum(prof[k]["launches"] for k in names if k in prof) / psteps
     chol_flops = m ** 3 / 3.0
     achieved = chol_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     traffic, traffic_src = None, None
     tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c3_hbm_traffic_pmc.json")))
     if m > 90000 and tfiles:                      # newest PMC pass of this same workload (tools/pmc_traffic.sh, offline)
         tj = json.load(open(tfiles[-1]))
-        traffic = tj["hbm_bytes_per_factorization_corrected"] / tj["launches_per_factorization"]
-        traffic_src = (f"profiles/{os.path.basename(tfiles[-1])} at commit {tj.get('commit')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
-                       "separate passes, FETCH x2 per the gfx950 note; bytes per gemm_nt* launch, mean over the launches of one "
-                       "factorization)")
+        if ("potrf_dag_kernel" in tj.get("kernels", {})) == dag:      # (a pass of the other schedule says nothing about this one)
+            traffic = tj["hbm_bytes_per_factorization_corrected"] / tj["launches_per_factorization"]
+            traffic_src = (f"profiles/{os.path.basename(tfiles[-1])} at commit {tj.get('commit')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                           "separate passes, FETCH x2 per the gfx950 note; bytes per launch of the factorization's kernels, mean over "
+                           "the launches of one factorization)")
     roof = {
         "bound": "mfma",
-        "kernel": "gemm_nt_big_kernel (K >= 2048: 93 % of the GEMM time at the headline size) + gemm_nt_kernel (persistent, K < 2048) + "
-                  "gemm_nt_small_kernel + gemm_nt_rows64_kernel: the syrk_gemm + trsm_gemm launches of one Cholesky factorization",
+        "kernel": ("potrf_dag_kernel: the whole Cholesky factorization as one persistent launch of left-looking tile tasks (128x128 "
+                   "tiles, the K-loop of gemm_nt_big_kernel), diagonal blocks and panel products included") if dag else
+                  ("gemm_nt_big_kernel (K >= 2048: 93 % of the GEMM time at the headline size) + gemm_nt_kernel (persistent, K < 2048) + "
+                   "gemm_nt_small_kernel + gemm_nt_rows64_kernel: the syrk_gemm + trsm_gemm launches of one Cholesky factorization"),
         "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
         "traffic": traffic, "traffic_source": traffic_src,
         "algorithmic_flops_per_step": chol_flops, "kernel_ms_per_step": gemm_ms, "launches_per_step": gemm_launches,

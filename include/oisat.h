@@ -329,6 +329,15 @@ int oisat_apply_increment(oisat_ctx* h, int dtype, const double* gxyz, const dou
                           const double* oxyz, const double* osig, const double* z, int64_t m, double g,
                           const void* xb, void* xa, void* inc, const double* glat, const double* olat_sorted);
 
+/* The same for cells that form a regular ny x nx grid (row-major, cell = y * nx + x): the kernel then takes compact 32-wide
+ * PATCHES of cells per workgroup instead of runs of consecutive cells, gives each patch a bounding sphere and skips the
+ * observations of the latitude window that lie beyond the covariance's reach (2^-64) of that sphere -- on a 0.25 deg grid at
+ * L = 300 km most of what the latitude window keeps: a polar cap's cells no longer visit the observations on the other
+ * side of the pole.  Same sums over the same observations in the same order (terms below 2^-64 of a term left out). */
+int oisat_apply_increment_grid(oisat_ctx* h, int dtype, const double* gxyz, const double* gsig, int64_t ny, int64_t nx,
+                               const double* oxyz, const double* osig, const double* z, int64_t m, double g,
+                               const void* xb, void* xa, void* inc, const double* glat, const double* olat_sorted);
+
 /* X <- X L^-T for nrows (multiple of 128) extra rows, X: dev float[nrows][ldx], ldx >= roundup(m,128).
  * Same MFMA GEMMs as the factorization (block forward substitution with the inverted diagonal blocks).
  * Must follow oisat_potrf of this L. */
@@ -346,6 +355,13 @@ int oisat_posterior_error(oisat_ctx* h, const float* L, int64_t m, int64_t ld, c
  * (the dense counterpart of AK = 1 - Sb/(Sa*reg), optimal_interpolation.py:31).  ak_out: dev double[m]. */
 int oisat_gain_diag(oisat_ctx* h, const float* L, int64_t m, int64_t ld, const double* ovar, int64_t chunk_rows,
                     double* ak_out);
+
+/* Schedule of the factorizations this handle runs from now on (oisat_potrf, batches made by oisat_batch_create): 1 = the
+ * task graph (ONE persistent launch of left-looking tile tasks, csrc/dense_dag.inc) wherever it applies, 0 = the recursion
+ * (one launch per node, lock-step over a batch), -1 (default) = by size: the task graph from three block rows up, unless the
+ * environment says otherwise (OISAT_DAG=0 | 1).  A caller that overlaps several batches on one GPU -- twelve months as two
+ * lock-step groups -- switches the task graph off for them: a persistent launch holds every workgroup slot until it is done. */
+int oisat_set_task_graph(oisat_ctx* h, int mode);
 
 /* How a handle's batched factorization shares the GPU with other handles' work that runs at the same time (several
  * groups of systems factored side by side, oisatgmi/dense.py BatchedFactor): wave_prio 0..3 = s_setprio of its kernels'
@@ -392,6 +408,9 @@ int oisat_batch_set_solve(oisat_ctx* h, int batch_id, int nmat, const double* co
                           double* const* work, void* const* state, const double* const* gxyz, const double* const* gsig,
                           const double* const* glat, const int64_t* n, const void* const* xb, void* const* xa,
                           void* const* inc);
+/* nx[i]: width of member i's cell grid (its n[i] cells are (n[i] / nx[i]) x nx[i], row-major; 0 = no such shape): the
+ * increment of oisat_batch_solve then works like oisat_apply_increment_grid.  After oisat_batch_set_solve. */
+int oisat_batch_set_grid(oisat_ctx* h, int batch_id, int nmat, const int64_t* nx);
 int oisat_batch_solve(oisat_ctx* h, int batch_id, int dtype, double g, int refine);
 int oisat_batch_destroy(oisat_ctx* h, int batch_id);
 int oisat_factor_adopt(oisat_ctx* h, const float* L, int64_t m, int64_t ld, float* tinv);

@@ -2140,12 +2140,14 @@ hipError_t dense_kernel_attributes() {
 
 // Which factorizations run as a task graph: systems of OISAT_DAG_MIN_BLOCKS .. OISAT_DAG_MAX_BLOCKS block rows (a single
 // system) / batches whose largest member has at most OISAT_DAG_MAX_BLOCKS; OISAT_DAG=0 turns it off, OISAT_DAG=1 forces it.
-// Above the upper bound the recursion's K >= 2048 GEMMs (8x8 tile patches per XCD, 0.88 of the MFMA peak) win.
+// Measured against the recursion (factorization alone, TFLOP/s): 10,000 observations 91.9 vs 53.9, 20,000: 126 vs 94,
+// 30,000: 135 vs 115, 50,000: 138 vs 128, 100,000: 140.8 vs 137.4 -- the task graph wins at every size, so there is no
+// upper bound by default; below three block rows there is nothing to overlap.
 // (read at every call: a plan is made once per system / batch, and tests switch the schedule inside one process)
-static inline bool dag_wanted(int64_t max_blocks, int nsys, int cu_count) {
-    const int kDagMode = getenv("OISAT_DAG") ? atoi(getenv("OISAT_DAG")) : -1;
+static inline bool dag_wanted(const oisat_ctx* h, int64_t max_blocks, int nsys, int cu_count) {
+    const int kDagMode = h->dag_mode >= 0 ? h->dag_mode : (getenv("OISAT_DAG") ? atoi(getenv("OISAT_DAG")) : -1);
     const int kDagMinBlocks = getenv("OISAT_DAG_MIN_BLOCKS") ? atoi(getenv("OISAT_DAG_MIN_BLOCKS")) : 3;
-    const int kDagMaxBlocks = getenv("OISAT_DAG_MAX_BLOCKS") ? atoi(getenv("OISAT_DAG_MAX_BLOCKS")) : 200;
+    const int kDagMaxBlocks = getenv("OISAT_DAG_MAX_BLOCKS") ? atoi(getenv("OISAT_DAG_MAX_BLOCKS")) : 1 << 20;
     if (kDagMode == 0) return false;
     if (nsys > (cu_count > 0 ? cu_count : 256) / 2) return false;      // every chain needs a running workgroup of its own
     if (kDagMode == 1) return max_blocks >= 2;
@@ -2159,6 +2161,12 @@ void oisat_dag_plan_release(void* plan) { dag_plan_free((DagPlan*)plan); }
 extern "C" int oisat_set_refine_tol(oisat_ctx* h, double tol) {
     ARG_CHECK(h != nullptr && tol >= 0.0 && tol < 1.0);
     h->refine_tol = tol;
+    return OISAT_OK;
+}
+
+extern "C" int oisat_set_task_graph(oisat_ctx* h, int mode) {
+    ARG_CHECK(h != nullptr && mode >= -1 && mode <= 1);
+    h->dag_mode = mode;
     return OISAT_OK;
 }
 
@@ -2208,7 +2216,7 @@ extern "C" int oisat_potrf(oisat_ctx* h, float* S, int64_t m, int64_t ld, int* i
         }
     }
     int rc;
-    if (!lookahead && !getenv("OISAT_POTRF") && dag_wanted(mpb, 1, h->cu_count)) {
+    if (!lookahead && !getenv("OISAT_POTRF") && dag_wanted(h, mpb, 1, h->cu_count)) {
         // the plan of this (S, tinv, ld, block rows) -- a handle keeps the last few (a lane that factors its tiles one after
         // the other in ONE shared buffer meets the same few sizes month after month)
         DagSingle* hit = nullptr;
@@ -2474,7 +2482,7 @@ extern "C" int oisat_batch_create(oisat_ctx* h, int nmat, float* const* S, const
             return OISAT_ENOMEM;
         }
     }
-    if (dag_wanted(bt->max_mpb, nmat, h->cu_count)) {
+    if (dag_wanted(h, bt->max_mpb, nmat, h->cu_count)) {
         bt->dag = dag_plan_create(bt->table, h->stream);
         if (!bt->dag) {
             (void)hipFree(bt->cum_dev);
@@ -2508,7 +2516,8 @@ extern "C" int oisat_batch_destroy(oisat_ctx* h, int batch_id) {
 }
 
 int oisat_cov_residual_batched(oisat_ctx* h, const SolveMember* mem_dev, int nmem, int64_t max_m, double g);
-int oisat_apply_increment_batched(oisat_ctx* h, int dtype, const SolveMember* mem_dev, int nmem, int64_t max_n, double g);
+int oisat_apply_increment_batched(oisat_ctx* h, int dtype, const SolveMember* mem_dev, const std::vector<SolveMember>& mem_host, int64_t max_n,
+                                  double g);
 
 extern "C" int oisat_batch_set_solve(oisat_ctx* h, int batch_id, int nmat, const double* const* oxyz, const double* const* osig,
                                      const double* const* ovar, const double* const* d, const double* const* olat, double* const* z,
@@ -2528,7 +2537,7 @@ extern "C" int oisat_batch_set_solve(oisat_ctx* h, int batch_id, int nmat, const
         ARG_CHECK(oxyz[c] && osig[c] && ovar[c] && d[c] && olat[c] && z[c] && work[c] && state[c] && gxyz[c] && gsig[c] && glat[c]);
         ARG_CHECK(n[c] > 0 && xb[c] && (xa[c] || inc[c]) && bm.mpb < 4096);
         SolveMember& sm = mem[i];
-        sm.S = bm.S; sm.tinv = bm.tinv; sm.ld = bm.ld; sm.m = bm.m; sm.mpb = bm.mpb; sm.pad = 0;
+        sm.S = bm.S; sm.tinv = bm.tinv; sm.ld = bm.ld; sm.m = bm.m; sm.mpb = bm.mpb; sm.nx = 0;
         sm.oxyz = oxyz[c]; sm.osig = osig[c]; sm.ovar = ovar[c]; sm.d = d[c]; sm.olat = olat[c];
         sm.z = z[c]; sm.rhs = work[c]; sm.fwd = work[c] + (int64_t)bm.mpb * NB; sm.st = (SolveState*)state[c];
         sm.gxyz = gxyz[c]; sm.gsig = gsig[c]; sm.glat = glat[c]; sm.n = n[c]; sm.xb = xb[c]; sm.xa = xa[c]; sm.inc = inc[c];
@@ -2547,10 +2556,29 @@ extern "C" int oisat_batch_set_solve(oisat_ctx* h, int batch_id, int nmat, const
     HIP_TRY(hipMalloc((void**)&bt->solve_dev, sizeof(SolveMember) * nmat));
     HIP_TRY(hipMalloc((void**)&bt->ord_dev, sizeof(int) * ord.size()));
     HIP_TRY(hipMalloc(&bt->ctl_dev, 2 * kCtlBytes));
+    bt->solve_host = mem;
+    bt->max_patches = 0;
     HIP_TRY(hipMemcpy(bt->solve_dev, mem.data(), sizeof(SolveMember) * nmat, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(bt->ord_dev, ord.data(), sizeof(int) * ord.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(bt->ctl_dev, 0, 2 * kCtlBytes));
     bt->ord_total = (int)ord.size();
+    return OISAT_OK;
+}
+
+// Width of every member's cell grid (its n cells are ny x nx, row-major), in the caller's member order; 0 = unknown.  The
+// increment then works on compact patches of cells and skips the observations beyond the covariance's reach of a patch.
+extern "C" int oisat_batch_set_grid(oisat_ctx* h, int batch_id, int nmat, const int64_t* nx) {
+    ARG_CHECK(h && nx && batch_id >= 0 && batch_id < (int)h->batches.size() && h->batches[batch_id]);
+    ChBatch* bt = h->batches[batch_id];
+    ARG_CHECK(nmat == (int)bt->table.size() && bt->solve_dev != nullptr && (int)bt->solve_host.size() == nmat);
+    for (int i = 0; i < nmat; ++i) {
+        const int64_t w = nx[bt->order[i]];
+        SolveMember& sm = bt->solve_host[i];
+        ARG_CHECK(w >= 0 && w < (int64_t)INT32_MAX && (w == 0 || sm.n % w == 0));
+        sm.nx = (int)w;
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(bt->solve_dev, bt->solve_host.data(), sizeof(SolveMember) * nmat, hipMemcpyHostToDevice));
     return OISAT_OK;
 }
 
@@ -2592,7 +2620,7 @@ extern "C" int oisat_batch_solve(oisat_ctx* h, int batch_id, int dtype, double g
         rc = sweeps(0, 1);
         if (rc) return rc;
     }
-    return oisat_apply_increment_batched(h, dtype, mem, nmem, bt.max_n, g);
+    return oisat_apply_increment_batched(h, dtype, mem, bt.solve_host, bt.max_n, g);
 }
 
 extern "C" int oisat_batch_potrf(oisat_ctx* h, int batch_id, int* info_host) {

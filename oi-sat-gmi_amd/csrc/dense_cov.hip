@@ -83,6 +83,95 @@ __device__ __forceinline__ int64_t lower_bound_lat(const double* __restrict__ a,
     return lo;
 }
 
+// ---- culling by distance (round 3) -------------------------------------------------------------------------------------
+// The latitude window keeps one contiguous range of the (latitude-ordered) observations per block of cells, but in
+// longitude it keeps everything: at L = 300 km and 0.25 deg most of the pairs it leaves are still further apart than the
+// chord at which 2^x < 2^-64 (a polar cap's cells see every observation of the cap's band, all around the pole).  The
+// increment kernel therefore gives its block of cells -- a compact PATCH of the grid -- a bounding sphere: centre c (normalised
+// mean of its points), radius rho (largest chord to c), and, while it stages the candidates of the window into LDS, keeps only
+// the observations with |q - c| <= cut + rho (|p - q| >= |q - c| - |p - c|: nothing closer than the cut-off is dropped).  A
+// test per (block, observation) instead of an exponential per (cell, observation); no latitudes, longitudes, poles or date
+// line in it.  The survivors are compacted in candidate order (wave ballots), so the sums keep a fixed order.
+// (The residual kernel's blocks are 64 consecutive observations in LATITUDE order -- all around the globe in longitude -- so a
+// sphere around them culls nothing; it keeps the plain window.)
+struct BlockSphere { double cx, cy, cz, r2cull; };
+
+// centre and cull radius of the block's live points (px, py, pz per thread and slot; every thread calls this)
+template <int SLOTS>
+__device__ __forceinline__ BlockSphere block_sphere(const double (&px)[SLOTS], const double (&py)[SLOTS], const double (&pz)[SLOTS],
+                                                    const bool (&live)[SLOTS], double cut_chord, double* __restrict__ red /*[16] shared*/) {
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+#pragma unroll
+    for (int q = 0; q < SLOTS; ++q)
+        if (live[q]) { sx += px[q]; sy += py[q]; sz += pz[q]; }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        sx += __shfl_xor(sx, o, kWave);
+        sy += __shfl_xor(sy, o, kWave);
+        sz += __shfl_xor(sz, o, kWave);
+    }
+    __syncthreads();
+    if (lane == 0) { red[w] = sx; red[4 + w] = sy; red[8 + w] = sz; }
+    __syncthreads();
+    sx = (red[0] + red[1]) + (red[2] + red[3]);
+    sy = (red[4] + red[5]) + (red[6] + red[7]);
+    sz = (red[8] + red[9]) + (red[10] + red[11]);
+    const double nrm = sqrt(sx * sx + sy * sy + sz * sz);
+    BlockSphere b;
+    if (!(nrm > 1e-9)) {                                        // points all around the sphere (or none): keep everything
+        b.cx = b.cy = b.cz = 0.0;
+        b.r2cull = 1e30;
+        return b;
+    }
+    b.cx = sx / nrm; b.cy = sy / nrm; b.cz = sz / nrm;
+    double r2 = 0.0;
+#pragma unroll
+    for (int q = 0; q < SLOTS; ++q)
+        if (live[q]) {
+            const double dx = px[q] - b.cx, dy = py[q] - b.cy, dz = pz[q] - b.cz;
+            r2 = fmax(r2, dx * dx + dy * dy + dz * dz);
+        }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) r2 = fmax(r2, __shfl_xor(r2, o, kWave));
+    __syncthreads();
+    if (lane == 0) red[12 + w] = r2;
+    __syncthreads();
+    r2 = fmax(fmax(red[12], red[13]), fmax(red[14], red[15]));
+    const double rr = cut_chord + sqrt(r2) * (1.0 + 1e-12) + 1e-12;
+    b.r2cull = cut_chord < 1e9 ? rr * rr : 1e30;
+    return b;
+}
+
+constexpr int kStage = 768;                                     // staged observations: processed once 512 have gathered
+
+// one pass of 256 candidates [c0, c0 + 256) /\ [.., j1): the near ones go to buf[fill ..) in candidate order; returns the new fill
+__device__ __forceinline__ int stage_near(const double* __restrict__ oxyz, const double* __restrict__ osig, const double* __restrict__ z,
+                                          int64_t m, int64_t c0, int64_t j1, const BlockSphere& bs, double2* __restrict__ bxy,
+                                          double2* __restrict__ bzw, int fill, int* __restrict__ wcnt /*[4] shared*/) {
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int64_t c = c0 + t;
+    double x = 0.0, y = 0.0, zz = 0.0;
+    bool near = false;
+    if (c < j1) {
+        x = oxyz[c]; y = oxyz[m + c]; zz = oxyz[2 * m + c];
+        const double dx = x - bs.cx, dy = y - bs.cy, dz = zz - bs.cz;
+        near = dx * dx + dy * dy + dz * dz <= bs.r2cull;
+    }
+    const unsigned long long mask = __ballot(near);
+    if (lane == 0) wcnt[w] = __popcll(mask);
+    __syncthreads();
+    const int c0w = wcnt[0], c1w = wcnt[1], c2w = wcnt[2], c3w = wcnt[3];
+    const int base = fill + (w > 0 ? c0w : 0) + (w > 1 ? c1w : 0) + (w > 2 ? c2w : 0);
+    if (near) {
+        const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+        bxy[pos] = make_double2(x, y);
+        bzw[pos] = make_double2(zz, osig[c] * z[c]);
+    }
+    __syncthreads();
+    return fill + c0w + c1w + c2w + c3w;
+}
+
 // ---- r = d - S z in double, S regenerated on the fly (iterative refinement) ----------------------
 // Block = 64 rows; 256 threads = 64 rows x 4 column phases; fixed-order combine (deterministic).
 // olat (optional): latitudes of the observations in degrees, ASCENDING -- the block's rows then span
@@ -171,6 +260,8 @@ __device__ __forceinline__ double exp2_neg(double x) {
 // CDNA4, so this costs a few extra issue slots per pair, not a factor.  exp2 stays fp32 (v_exp_f32); the
 // product with sig*z and the running sum are double, because the terms cancel: sum|term| reaches several
 // hundred times the field scale at swath densities, so fp32 partial sums alone cost ~1e-5.
+// Cells per block: a 32-wide patch of the (ny x nx) grid (nx > 0: CELLS * 8 rows x 32 columns -- a compact patch has a small
+// bounding sphere, 512 consecutive cells of a 1440-wide row span 128 degrees), or CELLS * 256 consecutive cells (nx = 0).
 template <typename T, int CELLS, bool BATCH>
 __global__ __launch_bounds__(256) void apply_increment_kernel(const double* __restrict__ gxyz, const double* __restrict__ gsig,
                                                                int64_t n, const double* __restrict__ oxyz,
@@ -178,11 +269,12 @@ __global__ __launch_bounds__(256) void apply_increment_kernel(const double* __re
                                                                int64_t m, double g2,
                                                                const T* __restrict__ xb, T* __restrict__ xa, T* __restrict__ inc,
                                                                const double* __restrict__ glat, const double* __restrict__ olat,
-                                                               double win_deg, const SolveMember* __restrict__ mem) {
+                                                               double win_deg, const SolveMember* __restrict__ mem, int nx,
+                                                               double cut_chord) {
     if (BATCH) {                                                // batched: blockIdx.y = member
         const SolveMember* mb = mem + blockIdx.y;
         n = mb->n;
-        if ((int64_t)blockIdx.x * CELLS * 256 >= n) return;
+        if (nx >= 0) nx = mb->nx;                                // (nx < 0: patches switched off)
         gxyz = mb->gxyz;
         gsig = mb->gsig;
         oxyz = mb->oxyz;
@@ -194,29 +286,50 @@ __global__ __launch_bounds__(256) void apply_increment_kernel(const double* __re
         inc = (T*)mb->inc;
         if (glat != nullptr) { glat = mb->glat; olat = mb->olat; }      // (non-null = "use the latitude window")
     }
-    constexpr int CH = 512;
-    __shared__ double2 sxy[CH], szw[CH];                    // (x, y) and (z, sig*z_solve)
+    constexpr int PW = 32, PH = CELLS * 8;
+    const int t = threadIdx.x;
+    int64_t cell[CELLS];
+    bool live[CELLS];
+    if (nx > 0) {                                               // patch (blockIdx.x) of the ny x nx grid
+        const int64_t ny = n / nx;
+        const int64_t ppr = (nx + PW - 1) / PW;                 // patches per row of patches
+        if ((int64_t)blockIdx.x >= ppr * ((ny + PH - 1) / PH)) return;
+        const int64_t py0 = ((int64_t)blockIdx.x / ppr) * PH, px0 = ((int64_t)blockIdx.x % ppr) * PW;
+#pragma unroll
+        for (int q = 0; q < CELLS; ++q) {
+            const int64_t yy = py0 + q * 8 + (t >> 5), xx = px0 + (t & 31);
+            live[q] = yy < ny && xx < nx;
+            cell[q] = yy * nx + xx;
+        }
+    } else {
+        if ((int64_t)blockIdx.x * CELLS * 256 >= n) return;
+#pragma unroll
+        for (int q = 0; q < CELLS; ++q) {
+            cell[q] = ((int64_t)blockIdx.x * CELLS + q) * 256 + t;
+            live[q] = cell[q] < n;
+        }
+    }
+    __shared__ double2 bxy[kStage], bzw[kStage];                // staged near observations: (x, y), (z, sig * z_solve)
+    __shared__ double red[16];
     __shared__ double s_lo[4], s_hi[4];
     __shared__ int64_t s_j[2];
-    const int t = threadIdx.x;
+    __shared__ int wcnt[4];
     double px[CELLS], py[CELLS], pz[CELLS];
     double acc[CELLS];
-    int64_t cell[CELLS];
 #pragma unroll
     for (int q = 0; q < CELLS; ++q) {
-        cell[q] = ((int64_t)blockIdx.x * CELLS + q) * 256 + t;
-        const bool live = cell[q] < n;
-        px[q] = live ? gxyz[cell[q]] : 0.0;
-        py[q] = live ? gxyz[n + cell[q]] : 0.0;
-        pz[q] = live ? gxyz[2 * n + cell[q]] : 0.0;
+        px[q] = live[q] ? gxyz[cell[q]] : 0.0;
+        py[q] = live[q] ? gxyz[n + cell[q]] : 0.0;
+        pz[q] = live[q] ? gxyz[2 * n + cell[q]] : 0.0;
         acc[q] = 0.0;
     }
     int64_t j0 = 0, j1 = m;
-    if (glat && olat) {                                     // latitude span of this block's cells -> observation index range
+    const bool windowed = glat && olat;
+    if (windowed) {                                             // latitude span of this block's cells -> observation index range
         double lo = 1e9, hi = -1e9;
 #pragma unroll
         for (int q = 0; q < CELLS; ++q)
-            if (cell[q] < n) { const double la = glat[cell[q]]; lo = fmin(lo, la); hi = fmax(hi, la); }
+            if (live[q]) { const double la = glat[cell[q]]; lo = fmin(lo, la); hi = fmax(hi, la); }
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) { lo = fmin(lo, __shfl_xor(lo, o, kWave)); hi = fmax(hi, __shfl_xor(hi, o, kWave)); }
         if ((t & 63) == 0) { s_lo[t >> 6] = lo; s_hi[t >> 6] = hi; }
@@ -231,34 +344,34 @@ __global__ __launch_bounds__(256) void apply_increment_kernel(const double* __re
         j0 = s_j[0];
         j1 = s_j[1];
     }
-    for (int64_t c0 = j0; c0 < j1; c0 += CH) {
-        __syncthreads();
-        for (int j = t; j < CH; j += 256) {
-            const int64_t c = c0 + j;
-            const bool live = c < j1;
-            sxy[j] = live ? make_double2(oxyz[c], oxyz[m + c]) : make_double2(0.0, 0.0);
-            szw[j] = live ? make_double2(oxyz[2 * m + c], osig[c] * z[c]) : make_double2(0.0, 0.0);
-        }
-        __syncthreads();
+    const BlockSphere bs = block_sphere<CELLS>(px, py, pz, live, windowed ? cut_chord : 1e30, red);
+    int fill = 0;
+    for (int64_t c0 = j0; c0 < j1 || fill > 0; c0 += 256) {
+        if (c0 < j1) fill = stage_near(oxyz, osig, z, m, c0, j1, bs, bxy, bzw, fill, wcnt);
+        if (fill >= 512 || c0 + 256 >= j1) {                    // block-uniform
 #pragma unroll 4
-        for (int j = 0; j < CH; ++j) {
-            const double2 oxy = sxy[j];
-            const double2 ozw = szw[j];
+            for (int j = 0; j < fill; ++j) {
+                const double2 oxy = bxy[j];
+                const double2 ozw = bzw[j];
 #pragma unroll
-            for (int q = 0; q < CELLS; ++q) {
-                const double dx = px[q] - oxy.x, dy = py[q] - oxy.y, dz = pz[q] - ozw.x;
-                // C = 2^x, x = -g2 |p - q|^2, in DOUBLE (exp2_neg, 2e-10).  Rounds 1-2 used v_exp_f32: good to 1 ulp = 1.2e-7 of the
-                // term, but the terms cancel (sum|term| is several hundred times the field at swath densities, more at larger L)
-                // and that alone put the fields 2.5e-6 of their scale off at 720x1440 / 1e5 obs, L = 300 km, and 1.3e-5 -- outside
-                // the 1e-5 bar -- at 360x720 / 1e4 gridded obs, L = 500 km; with this: 4e-8.  Costs twice the kernel time
-                // (taking only the pairs with C > 2^-8 in double diverges inside the waves and is slower still at L = 500 km).
-                acc[q] += exp2_neg(-g2 * (dx * dx + dy * dy + dz * dz)) * ozw.y;
+                for (int q = 0; q < CELLS; ++q) {
+                    const double dx = px[q] - oxy.x, dy = py[q] - oxy.y, dz = pz[q] - ozw.x;
+                    // C = 2^x, x = -g2 |p - q|^2, in DOUBLE (exp2_neg, 2e-10).  Rounds 1-2 used v_exp_f32: good to 1 ulp = 1.2e-7 of
+                    // the term, but the terms cancel (sum|term| is several hundred times the field at swath densities, more at
+                    // larger L) and that alone put the fields 2.5e-6 of their scale off at 720x1440 / 1e5 obs, L = 300 km, and
+                    // 1.3e-5 -- outside the 1e-5 bar -- at 360x720 / 1e4 gridded obs, L = 500 km; with this: 4e-8.  Twice the
+                    // instructions per pair (taking only the pairs with C > 2^-8 in double diverges inside the waves and is
+                    // slower still at L = 500 km); the bounding-sphere cull above pays for it.
+                    acc[q] += exp2_neg(-g2 * (dx * dx + dy * dy + dz * dz)) * ozw.y;
+                }
             }
+            fill = 0;
+            __syncthreads();
         }
     }
 #pragma unroll
     for (int q = 0; q < CELLS; ++q) {
-        if (cell[q] < n) {
+        if (live[q]) {
             const double v = gsig[cell[q]] * acc[q];
             if (inc) inc[cell[q]] = (T)v;
             if (xa) xa[cell[q]] = (T)((double)xb[cell[q]] + v);
@@ -317,31 +430,61 @@ static inline int increment_cells(const oisat_ctx* h, int64_t n, int nmem) {
     return wgs2 < 4 * (int64_t)(h->cu_count > 0 ? h->cu_count : 256) ? 1 : 2;
 }
 
+// workgroups of one system: patches of 32 x (8 CELLS) cells of its ny x nx grid (nx > 0) or runs of 256 CELLS cells
+static inline bool increment_patches() {                   // OISAT_INC_PATCH=0: runs of consecutive cells whatever the grid (experiments)
+    static const bool on = !getenv("OISAT_INC_PATCH") || atoi(getenv("OISAT_INC_PATCH")) != 0;
+    return on;
+}
+static inline int64_t increment_blocks(int64_t n, int64_t nx, int cells) {
+    if (nx > 0 && increment_patches()) return cdiv(nx, 32) * cdiv(n / nx, 8 * cells);
+    return cdiv(n, 256 * cells);
+}
+
+// chord beyond which 2^(-g2 chord^2) < 2^-64 (the same cut-off as the latitude window's)
+static inline double cut_chord_of(double g2) { return sqrt(64.0 / g2); }
+
 template <typename T, int CELLS, bool BATCH>
-static int increment_launch(oisat_ctx* h, unsigned gy, const double* gxyz, const double* gsig, int64_t n, const double* oxyz,
+static int increment_launch(oisat_ctx* h, unsigned gx, unsigned gy, const double* gxyz, const double* gsig, int64_t n, int nx, const double* oxyz,
                             const double* osig, const double* z, int64_t m, double g2, const void* xb, void* xa, void* inc,
                             const double* glat, const double* olat, double win, const SolveMember* mem) {
-    const unsigned gx = (unsigned)cdiv(n, 256 * CELLS);
     OISAT_LAUNCH(h, "apply_increment", (apply_increment_kernel<T, CELLS, BATCH>), dim3(gx, gy), dim3(256), 0, gxyz, gsig, n, oxyz, osig, z,
-                 m, g2, (const T*)xb, (T*)xa, (T*)inc, glat, olat, win, mem);
+                 m, g2, (const T*)xb, (T*)xa, (T*)inc, glat, olat, win, mem, increment_patches() ? nx : -1, cut_chord_of(g2));
     return OISAT_OK;
+}
+
+// nx > 0: the n cells are a (n / nx) x nx grid, row-major (oisat_apply_increment_grid); 0: no known shape
+static int apply_increment_impl(oisat_ctx* h, int dtype, const double* gxyz, const double* gsig, int64_t n, int64_t nx, const double* oxyz,
+                                const double* osig, const double* z, int64_t m, double g, const void* xb, void* xa, void* inc,
+                                const double* glat, const double* olat_sorted) {
+    ARG_CHECK(h && gxyz && gsig && oxyz && osig && z && n > 0 && m > 0 && (xa || inc));
+    ARG_CHECK(!xa || xb);
+    ARG_CHECK(dtype == OISAT_F32 || dtype == OISAT_F64);
+    ARG_CHECK(nx >= 0 && nx < (int64_t)INT32_MAX && (nx == 0 || n % nx == 0));
+    const double g2 = g * (double)kLog2e;
+    const double win = lat_window_deg(g2);
+    if (!(win < 180.0) || !glat || !olat_sorted) { glat = nullptr; olat_sorted = nullptr; }
+    const int cells = increment_cells(h, n, 1);
+    const int64_t gx = increment_blocks(n, nx, cells);
+    ARG_CHECK(gx < (int64_t)INT32_MAX);
+    const unsigned ux = (unsigned)gx;
+    if (dtype == OISAT_F32)
+        return cells == 1 ? increment_launch<float, 1, false>(h, ux, 1, gxyz, gsig, n, (int)nx, oxyz, osig, z, m, g2, xb, xa, inc, glat, olat_sorted, win, nullptr)
+                          : increment_launch<float, 2, false>(h, ux, 1, gxyz, gsig, n, (int)nx, oxyz, osig, z, m, g2, xb, xa, inc, glat, olat_sorted, win, nullptr);
+    return cells == 1 ? increment_launch<double, 1, false>(h, ux, 1, gxyz, gsig, n, (int)nx, oxyz, osig, z, m, g2, xb, xa, inc, glat, olat_sorted, win, nullptr)
+                      : increment_launch<double, 2, false>(h, ux, 1, gxyz, gsig, n, (int)nx, oxyz, osig, z, m, g2, xb, xa, inc, glat, olat_sorted, win, nullptr);
 }
 
 extern "C" int oisat_apply_increment(oisat_ctx* h, int dtype, const double* gxyz, const double* gsig, int64_t n,
                                      const double* oxyz, const double* osig, const double* z, int64_t m, double g,
                                      const void* xb, void* xa, void* inc, const double* glat, const double* olat_sorted) {
-    ARG_CHECK(h && gxyz && gsig && oxyz && osig && z && n > 0 && m > 0 && (xa || inc));
-    ARG_CHECK(!xa || xb);
-    ARG_CHECK(dtype == OISAT_F32 || dtype == OISAT_F64);
-    const double g2 = g * (double)kLog2e;
-    const double win = lat_window_deg(g2);
-    if (!(win < 180.0) || !glat || !olat_sorted) { glat = nullptr; olat_sorted = nullptr; }
-    const int cells = increment_cells(h, n, 1);
-    if (dtype == OISAT_F32)
-        return cells == 1 ? increment_launch<float, 1, false>(h, 1, gxyz, gsig, n, oxyz, osig, z, m, g2, xb, xa, inc, glat, olat_sorted, win, nullptr)
-                          : increment_launch<float, 2, false>(h, 1, gxyz, gsig, n, oxyz, osig, z, m, g2, xb, xa, inc, glat, olat_sorted, win, nullptr);
-    return cells == 1 ? increment_launch<double, 1, false>(h, 1, gxyz, gsig, n, oxyz, osig, z, m, g2, xb, xa, inc, glat, olat_sorted, win, nullptr)
-                      : increment_launch<double, 2, false>(h, 1, gxyz, gsig, n, oxyz, osig, z, m, g2, xb, xa, inc, glat, olat_sorted, win, nullptr);
+    return apply_increment_impl(h, dtype, gxyz, gsig, n, 0, oxyz, osig, z, m, g, xb, xa, inc, glat, olat_sorted);
+}
+
+extern "C" int oisat_apply_increment_grid(oisat_ctx* h, int dtype, const double* gxyz, const double* gsig, int64_t ny, int64_t nx,
+                                          const double* oxyz, const double* osig, const double* z, int64_t m, double g,
+                                          const void* xb, void* xa, void* inc, const double* glat, const double* olat_sorted) {
+    ARG_CHECK(ny > 0 && nx > 0);
+    return apply_increment_impl(h, dtype, gxyz, gsig, ny * nx, nx, oxyz, osig, z, m, g, xb, xa, inc, glat, olat_sorted);
 }
 
 // ---- batched forms (oisat_batch_solve, dense_chol.hip): blockIdx.y = member of the device table --------------------------
@@ -355,16 +498,21 @@ int oisat_cov_residual_batched(oisat_ctx* h, const SolveMember* mem_dev, int nme
     return OISAT_OK;
 }
 
-int oisat_apply_increment_batched(oisat_ctx* h, int dtype, const SolveMember* mem_dev, int nmem, int64_t max_n, double g) {
+int oisat_apply_increment_batched(oisat_ctx* h, int dtype, const SolveMember* mem_dev, const std::vector<SolveMember>& mem_host, int64_t max_n,
+                                  double g) {
     const double g2 = g * (double)kLog2e;
     const double win = lat_window_deg(g2);
     static const double dummy = 0.0;
     const double* use = win < 180.0 ? &dummy : (const double*)nullptr;
+    const int nmem = (int)mem_host.size();
     const int cells = increment_cells(h, max_n, nmem);
-    const unsigned gy = (unsigned)nmem;
+    int64_t gx = 0;                                         // workgroups of the member that needs the most
+    for (const SolveMember& sm : mem_host) gx = std::max(gx, increment_blocks(sm.n, sm.nx, cells));
+    ARG_CHECK(gx > 0 && gx < (int64_t)INT32_MAX);
+    const unsigned ux = (unsigned)gx, gy = (unsigned)nmem;
     if (dtype == OISAT_F32)
-        return cells == 1 ? increment_launch<float, 1, true>(h, gy, nullptr, nullptr, max_n, nullptr, nullptr, nullptr, 0, g2, nullptr, nullptr, nullptr, use, use, win, mem_dev)
-                          : increment_launch<float, 2, true>(h, gy, nullptr, nullptr, max_n, nullptr, nullptr, nullptr, 0, g2, nullptr, nullptr, nullptr, use, use, win, mem_dev);
-    return cells == 1 ? increment_launch<double, 1, true>(h, gy, nullptr, nullptr, max_n, nullptr, nullptr, nullptr, 0, g2, nullptr, nullptr, nullptr, use, use, win, mem_dev)
-                      : increment_launch<double, 2, true>(h, gy, nullptr, nullptr, max_n, nullptr, nullptr, nullptr, 0, g2, nullptr, nullptr, nullptr, use, use, win, mem_dev);
+        return cells == 1 ? increment_launch<float, 1, true>(h, ux, gy, nullptr, nullptr, max_n, 0, nullptr, nullptr, nullptr, 0, g2, nullptr, nullptr, nullptr, use, use, win, mem_dev)
+                          : increment_launch<float, 2, true>(h, ux, gy, nullptr, nullptr, max_n, 0, nullptr, nullptr, nullptr, 0, g2, nullptr, nullptr, nullptr, use, use, win, mem_dev);
+    return cells == 1 ? increment_launch<double, 1, true>(h, ux, gy, nullptr, nullptr, max_n, 0, nullptr, nullptr, nullptr, 0, g2, nullptr, nullptr, nullptr, use, use, win, mem_dev)
+                      : increment_launch<double, 2, true>(h, ux, gy, nullptr, nullptr, max_n, 0, nullptr, nullptr, nullptr, 0, g2, nullptr, nullptr, nullptr, use, use, win, mem_dev);
 }

@@ -56,7 +56,7 @@ struct SolveMember {             // one system of a batched solve phase (device 
     const float* S;              // its factor (after oisat_batch_potrf) and inverted diagonal blocks
     const float* tinv;
     int64_t ld, m;
-    int mpb, pad;
+    int mpb, nx;                 // block rows; width of the system's (ny x nx, row-major) cell grid, 0 = unknown (oisat_batch_set_grid)
     const double *oxyz, *osig, *ovar, *d, *olat;       // observations (ascending latitude), innovation
     double *z, *rhs, *fwd;       // solution; padded right-hand side and forward solution [mpb * 128] each
     SolveState* st;
@@ -80,6 +80,8 @@ struct ChBatch {                 // matrices factored in lock-step by oisat_batc
     // batched solve phase (oisat_batch_set_solve): member table in the order of `table`, the sweep's ticket -> (member, step)
     // list (steps ascending, so that a row only waits for lower tickets) and two control blocks (forward | backward)
     SolveMember* solve_dev = nullptr;
+    std::vector<SolveMember> solve_host;
+    int64_t max_patches = 0;
     int* ord_dev = nullptr;
     void* ctl_dev = nullptr;
     int ord_total = 0;
@@ -128,6 +130,7 @@ struct oisat_ctx {
     hipEvent_t signal_event = nullptr;  // oisat_wait_for: recorded on this handle's stream, waited on by another handle's
     std::vector<ChBatch*> batches;      // oisat_batch_create
     // task-graph plans of the last single-system factorizations on this handle (dense_dag.inc), keyed by what a plan depends on
+    int dag_mode = -1;                  // oisat_set_task_graph: -1 = by size (and OISAT_DAG), 0 = recursion only, 1 = task graph wherever it applies
     DagSingle dag_cache[8];
     uint64_t dag_clock = 0;
     // pinned host scratch for small synchronous read-backs

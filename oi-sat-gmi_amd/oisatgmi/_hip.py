@@ -94,10 +94,14 @@ SIGNATURES = {
     "oisat_gain_diag": (C.c_int, [_c_ctx, _ptr, _i64, _i64, _ptr, _i64, _ptr]),
     "oisat_apply_increment": (C.c_int, [_c_ctx, C.c_int, _ptr, _ptr, _i64, _ptr, _ptr, _ptr, _i64, C.c_double, _ptr,
                                         _ptr, _ptr, _ptr, _ptr]),
+    "oisat_apply_increment_grid": (C.c_int, [_c_ctx, C.c_int, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _i64, C.c_double, _ptr,
+                                             _ptr, _ptr, _ptr, _ptr]),
     "oisat_batch_create": (C.c_int, [_c_ctx, C.c_int, C.POINTER(_ptr), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_ptr),
                                      C.POINTER(C.c_int)]),
     "oisat_batch_potrf": (C.c_int, [_c_ctx, C.c_int, C.POINTER(C.c_int)]),
     "oisat_batch_set_solve": (C.c_int, [_c_ctx, C.c_int, C.c_int] + [C.POINTER(_ptr)] * 11 + [C.POINTER(_i64)] + [C.POINTER(_ptr)] * 3),
+    "oisat_set_task_graph": (C.c_int, [_c_ctx, C.c_int]),
+    "oisat_batch_set_grid": (C.c_int, [_c_ctx, C.c_int, C.c_int, C.POINTER(_i64)]),
     "oisat_batch_solve": (C.c_int, [_c_ctx, C.c_int, C.c_int, C.c_double, C.c_int]),
     "oisat_batch_destroy": (C.c_int, [_c_ctx, C.c_int]),
     "oisat_factor_adopt": (C.c_int, [_c_ctx, _ptr, _i64, _i64, _ptr]),

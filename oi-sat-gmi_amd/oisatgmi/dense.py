@@ -68,6 +68,7 @@ class DenseAnalysis:
         self.dt = np.dtype(dtype)
         self.code = _hip.dtype_code(self.dt)
         self.shape = np.shape(grid_lat)
+        self._ny, self._nx = (self.shape if len(self.shape) == 2 else (1, int(np.size(grid_lat))))   # cells as a ny x nx grid
         self.n = int(np.size(grid_lat))
         self.max_obs = int(max_obs)
         self.mp_max = -(-self.max_obs // NB) * NB
@@ -186,8 +187,8 @@ class DenseAnalysis:
         resid = (C.c_double * (refine + 1))() if want_resid else None
         c.check(lib.oisat_gain_solve(h, self.S.ptr, self.oxyz.ptr, self.osig.ptr, self.ovar.ptr, m, ld, g, self.d.ptr,
                                      int(refine), self.z.ptr, resid, self.olat.ptr))
-        c.check(lib.oisat_apply_increment(h, self.code, self.gxyz.ptr, self.gsig.ptr, self.n, self.oxyz.ptr,
-                                          self.osig.ptr, self.z.ptr, m, g, xb, xa, inc, self.glat.ptr, self.olat.ptr))
+        c.check(lib.oisat_apply_increment_grid(h, self.code, self.gxyz.ptr, self.gsig.ptr, self._ny, self._nx, self.oxyz.ptr,
+                                               self.osig.ptr, self.z.ptr, m, g, xb, xa, inc, self.glat.ptr, self.olat.ptr))
         return list(resid) if want_resid else None
 
     # ---- the same pipeline in two halves, for lock-step (batched) factorization of many plans: build | factor | solve
@@ -210,8 +211,8 @@ class DenseAnalysis:
         c.check(lib.oisat_factor_adopt(h, self.S.ptr, m, ld, self.tinv.ptr))
         c.check(lib.oisat_gain_solve(h, self.S.ptr, self.oxyz.ptr, self.osig.ptr, self.ovar.ptr, m, ld, g, self.d.ptr,
                                      int(refine), self.z.ptr, None, self.olat.ptr))
-        c.check(lib.oisat_apply_increment(h, self.code, self.gxyz.ptr, self.gsig.ptr, self.n, self.oxyz.ptr,
-                                          self.osig.ptr, self.z.ptr, m, g, xb, xa, inc, self.glat.ptr, self.olat.ptr))
+        c.check(lib.oisat_apply_increment_grid(h, self.code, self.gxyz.ptr, self.gsig.ptr, self._ny, self._nx, self.oxyz.ptr,
+                                               self.osig.ptr, self.z.ptr, m, g, xb, xa, inc, self.glat.ptr, self.olat.ptr))
 
     # ---- posterior diagnostics (after run(); they reuse the factor that run() left in HBM)
     def posterior_error(self, chunk_rows: int = 4096):
@@ -309,8 +310,11 @@ class BatchedFactor:
         # all systems drawn from one list -- so the groups are simply runs of at most OISAT_DAG_GROUP systems (default 96;
         # the library takes up to half the CU count) in order of size.  Without it: lock-step recursion, which wants groups
         # of comparable block count.
+        # Batches of more than OISAT_DAG_MAX_SYSTEMS (default 128: twelve months = 600 units) keep the lock-step recursion: its
+        # two groups overlap each other's solves, which a sequence of persistent launches does not (measured: 0.69 vs 1.03 s).
         self.dag = (os.environ.get("OISAT_DAG", "-1") != "0" and bool(order)
-                    and order[0].mp // NB <= int(os.environ.get("OISAT_DAG_MAX_BLOCKS", "200")))
+                    and len(order) <= int(os.environ.get("OISAT_DAG_MAX_SYSTEMS", "128"))
+                    and order[0].mp // NB <= int(os.environ.get("OISAT_DAG_MAX_BLOCKS", str(1 << 20))))
         if self.dag:
             per = max(1, int(os.environ.get("OISAT_DAG_GROUP", "96")))
             groups = [order[i:i + per] for i in range(0, len(order), per)]
@@ -355,6 +359,7 @@ class BatchedFactor:
         self.ids = []
         for g, ctx in zip(self.groups, self.ctxs):
             n = len(g)
+            ctx.check(ctx.lib.oisat_set_task_graph(ctx.h, -1 if self.dag else 0))
             Sp = (C.c_void_p * n)(*[p.S.ptr for p in g])
             Tp = (C.c_void_p * n)(*[p.tinv.ptr for p in g])
             mm = (C.c_int64 * n)(*[p.m for p in g])
@@ -371,6 +376,7 @@ class BatchedFactor:
                     arr([p.work.ptr for p in g]), arr([p.state.ptr for p in g]), arr([p.gxyz.ptr for p in g]),
                     arr([p.gsig.ptr for p in g]), arr([p.glat.ptr for p in g]), (C.c_int64 * n)(*[p.n for p in g]),
                     arr([p.xb_ptr for p in g]), arr([p.out_ptr for p in g]), arr([p.out_ptr + p.n * item for p in g])))
+                ctx.check(ctx.lib.oisat_batch_set_grid(ctx.h, bid.value, n, (C.c_int64 * n)(*[p._nx for p in g])))
         self.group_of = {id(p): gi for gi, g in enumerate(self.groups) for p in g}
         self._threads = None
         # measured, one box (1 month of 720x1440 / 1e5 obs; a rank's eighth of 12 months; all 12 months):

@@ -242,6 +242,7 @@ def test_batched_factorization_with_leaf_pairs(ctx):
     second block of a pair."""
     from oisatgmi import dense
     lib = ctx.lib
+    ctx.check(lib.oisat_set_task_graph(ctx.h, 0))            # the recursion (tests/test_gpu_dag.py has the task graph's twin of this test)
     sizes = [2100, 1500, 1290, 1000, 777, 640, 300, 257, 129, 100]
     mats, refs = [], []
     for k, m in enumerate(sizes):
@@ -296,6 +297,7 @@ def test_batched_factorization_with_leaf_pairs(ctx):
             ctx.check(lib.oisat_batch_potrf(ctx.h, bid.value, info2))
         ctx.solve_status(clear=True)
         ctx.check(lib.oisat_batch_destroy(ctx.h, bid.value))
+    ctx.check(lib.oisat_set_task_graph(ctx.h, -1))
 
 
 def test_oi_dense_mode_through_the_facade_at_config2_size(ctx):

@@ -28,7 +28,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 for k, v in ker.items():
     v["bytes_per_dispatch"] = (v["fetch_bytes_corrected"] + v["write_bytes"]) / max(v["dispatches"], 1)
 out["kernels"] = dict(sorted(ker.items(), key=lambda kv: -(kv[1]["fetch_bytes_corrected"] + kv[1]["write_bytes"])))
-gemm = [v for k, v in ker.items() if k.startswith("gemm_nt")]
+gemm = [v for k, v in ker.items() if k.startswith("gemm_nt") or k.startswith("potrf_dag")]      # the factorization's kernels
 if gemm and nfact > 0:
     tot = sum(v["fetch_bytes_corrected"] + v["write_bytes"] for v in gemm)
     nl = sum(v["dispatches"] for v in gemm)
@@ -39,4 +39,4 @@ json.dump(out, open(f"gpurun_out/{tag}_hbm_traffic_pmc.json", "w"), indent=1)
 for k, v in list(out["kernels"].items())[:8]:
     print("%-44s x%-6d fetch %10.1f MB  write %10.1f MB  per dispatch %9.2f MB" % (k, v["dispatches"], v["fetch_bytes_corrected"] / 1e6, v["write_bytes"] / 1e6, v["bytes_per_dispatch"] / 1e6))
 if "hbm_bytes_per_factorization_corrected" in out:
-    print("GEMMs: %.2f TB per factorization, %.0f launches, %.2f GB per launch" % (out["hbm_bytes_per_factorization_corrected"] / 1e12, out["launches_per_factorization"], out["gemm_bytes_per_launch"] / 1e9))
+    print("factorization kernels: %.2f TB per factorization, %.0f launches, %.2f GB per launch" % (out["hbm_bytes_per_factorization_corrected"] / 1e12, out["launches_per_factorization"], out["gemm_bytes_per_launch"] / 1e9))
