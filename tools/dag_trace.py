@@ -46,13 +46,14 @@ def report(path):
         if nb < 3:
             continue
         full = s[1:-1]                                   # steps with all six stamps
-        ph = {"wait pre": full[:, 1] - full[:, 0], "acquire + update": full[:, 2] - full[:, 1], "diagonal block + publish": full[:, 3] - full[:, 2],
-              "wait sub": full[:, 4] - full[:, 3], "acquire + panel tile + publish": full[:, 5] - full[:, 4]}
+        ph = {"diagonal block + publish": full[:, 1] - full[:, 0], "wait sub(j)": full[:, 2] - full[:, 1],
+              "panel product + store + image + publish": full[:, 3] - full[:, 2], "rank-128 update from LDS": full[:, 4] - full[:, 3],
+              "wait pre(j+1)": full[:, 5] - full[:, 4], "write-back + barrier": np.concatenate([s[2:-1, 0] - full[:-1, 5], [0]])}
         step = (s[1:, 0] - s[:-1, 0]) * us
         print("chain of system %d: %d blocks, %.1f us per block (median %.1f); total %.1f us"
               % (sysid, nb, step.mean(), np.median(step), (s[-1, 3] - s[0, 0]) * us))
         for k, v in ph.items():
-            print("    %-32s mean %6.2f us   median %6.2f   max %7.2f" % (k, v.mean() * us, np.median(v) * us, v.max() * us))
+            print("    %-40s mean %6.2f us   median %6.2f   max %7.2f" % (k, v.mean() * us, np.median(v) * us, v.max() * us))
         if c > 3:
             break
     # workgroups computing at a time (bulk tasks; the polling time is taken off the end of a task's interval)
