@@ -338,6 +338,14 @@ int oisat_apply_increment_grid(oisat_ctx* h, int dtype, const double* gxyz, cons
                                const double* oxyz, const double* osig, const double* z, int64_t m, double g,
                                const void* xb, void* xa, void* inc, const double* glat, const double* olat_sorted);
 
+/* perm: dev int32[m], a permutation of 0 .. m-1 that lists the observations (indices into the ascending-latitude order
+ * they are stored in) along a space-filling curve, so that 64 consecutive entries are neighbours in space.  The float64
+ * residual of the gain solves that follow on this handle for systems of exactly m observations (oisat_gain_solve,
+ * oisat_cov_residual) then takes its blocks of 64 rows from this list: a block has a small bounding sphere, and of the
+ * latitude window's observations only those within the covariance's reach (2^-64) of it are visited -- the residual's rows
+ * are otherwise 64 consecutive LATITUDES, all around the globe.  Same terms per row in the same order.  NULL / m = 0 clears. */
+int oisat_set_obs_blocks(oisat_ctx* h, const int32_t* perm, int64_t m);
+
 /* X <- X L^-T for nrows (multiple of 128) extra rows, X: dev float[nrows][ldx], ldx >= roundup(m,128).
  * Same MFMA GEMMs as the factorization (block forward substitution with the inverted diagonal blocks).
  * Must follow oisat_potrf of this L. */
@@ -409,8 +417,10 @@ int oisat_batch_set_solve(oisat_ctx* h, int batch_id, int nmat, const double* co
                           const double* const* glat, const int64_t* n, const void* const* xb, void* const* xa,
                           void* const* inc);
 /* nx[i]: width of member i's cell grid (its n[i] cells are (n[i] / nx[i]) x nx[i], row-major; 0 = no such shape): the
- * increment of oisat_batch_solve then works like oisat_apply_increment_grid.  After oisat_batch_set_solve. */
-int oisat_batch_set_grid(oisat_ctx* h, int batch_id, int nmat, const int64_t* nx);
+ * increment of oisat_batch_solve then works like oisat_apply_increment_grid.  perm (may be NULL, entries may be NULL):
+ * perm[i] = member i's observations along a space-filling curve, dev int32[m_i] (see oisat_set_obs_blocks): its float64
+ * residuals then run on compact blocks of rows.  After oisat_batch_set_solve. */
+int oisat_batch_set_grid(oisat_ctx* h, int batch_id, int nmat, const int64_t* nx, const int32_t* const* perm);
 int oisat_batch_solve(oisat_ctx* h, int batch_id, int dtype, double g, int refine);
 int oisat_batch_destroy(oisat_ctx* h, int batch_id);
 int oisat_factor_adopt(oisat_ctx* h, const float* L, int64_t m, int64_t ld, float* tinv);

@@ -2515,7 +2515,7 @@ extern "C" int oisat_batch_destroy(oisat_ctx* h, int batch_id) {
     return OISAT_OK;
 }
 
-int oisat_cov_residual_batched(oisat_ctx* h, const SolveMember* mem_dev, int nmem, int64_t max_m, double g);
+int oisat_cov_residual_batched(oisat_ctx* h, const SolveMember* mem_dev, const std::vector<SolveMember>& mem_host, int64_t max_m, double g);
 int oisat_apply_increment_batched(oisat_ctx* h, int dtype, const SolveMember* mem_dev, const std::vector<SolveMember>& mem_host, int64_t max_n,
                                   double g);
 
@@ -2541,6 +2541,7 @@ extern "C" int oisat_batch_set_solve(oisat_ctx* h, int batch_id, int nmat, const
         sm.oxyz = oxyz[c]; sm.osig = osig[c]; sm.ovar = ovar[c]; sm.d = d[c]; sm.olat = olat[c];
         sm.z = z[c]; sm.rhs = work[c]; sm.fwd = work[c] + (int64_t)bm.mpb * NB; sm.st = (SolveState*)state[c];
         sm.gxyz = gxyz[c]; sm.gsig = gsig[c]; sm.glat = glat[c]; sm.n = n[c]; sm.xb = xb[c]; sm.xa = xa[c]; sm.inc = inc[c];
+        sm.perm = nullptr;
         if (bm.m > bt->max_m) bt->max_m = bm.m;
         if (n[c] > bt->max_n) bt->max_n = n[c];
         if ((int64_t)bm.mpb * NB > bt->max_mp) bt->max_mp = (int64_t)bm.mpb * NB;
@@ -2567,7 +2568,9 @@ extern "C" int oisat_batch_set_solve(oisat_ctx* h, int batch_id, int nmat, const
 
 // Width of every member's cell grid (its n cells are ny x nx, row-major), in the caller's member order; 0 = unknown.  The
 // increment then works on compact patches of cells and skips the observations beyond the covariance's reach of a patch.
-extern "C" int oisat_batch_set_grid(oisat_ctx* h, int batch_id, int nmat, const int64_t* nx) {
+// perm (optional; entries may be NULL): member i's observations along a space-filling curve (dev int32[m_i], a permutation
+// of its latitude order): the float64 residual then works on compact blocks of rows with the same cull.
+extern "C" int oisat_batch_set_grid(oisat_ctx* h, int batch_id, int nmat, const int64_t* nx, const int32_t* const* perm) {
     ARG_CHECK(h && nx && batch_id >= 0 && batch_id < (int)h->batches.size() && h->batches[batch_id]);
     ChBatch* bt = h->batches[batch_id];
     ARG_CHECK(nmat == (int)bt->table.size() && bt->solve_dev != nullptr && (int)bt->solve_host.size() == nmat);
@@ -2576,6 +2579,7 @@ extern "C" int oisat_batch_set_grid(oisat_ctx* h, int batch_id, int nmat, const 
         SolveMember& sm = bt->solve_host[i];
         ARG_CHECK(w >= 0 && w < (int64_t)INT32_MAX && (w == 0 || sm.n % w == 0));
         sm.nx = (int)w;
+        sm.perm = perm ? perm[bt->order[i]] : nullptr;
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpy(bt->solve_dev, bt->solve_host.data(), sizeof(SolveMember) * nmat, hipMemcpyHostToDevice));
@@ -2614,7 +2618,7 @@ extern "C" int oisat_batch_solve(oisat_ctx* h, int batch_id, int dtype, double g
     int rc = sweeps(1, 0);
     if (rc) return rc;
     for (int it = 0; it < refine; ++it) {
-        rc = oisat_cov_residual_batched(h, mem, nmem, bt.max_m, g);
+        rc = oisat_cov_residual_batched(h, mem, bt.solve_host, bt.max_m, g);
         if (rc) return rc;
         OISAT_LAUNCH(h, "resid_check", resid_check_batched_kernel, dim3((unsigned)nmem), dim3(1024), 0, mem, it, tol * tol);
         rc = sweeps(0, 1);

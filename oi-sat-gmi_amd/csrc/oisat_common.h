@@ -65,6 +65,7 @@ struct SolveMember {             // one system of a batched solve phase (device 
     const void* xb;              // background, analysis, increment (dtype of the batch)
     void* xa;
     void* inc;
+    const int* perm;             // its observations along a space-filling curve (compact residual blocks) or nullptr
 };
 
 struct ChBatch {                 // matrices factored in lock-step by oisat_batch_potrf (sorted by block count, largest first)
@@ -130,6 +131,8 @@ struct oisat_ctx {
     hipEvent_t signal_event = nullptr;  // oisat_wait_for: recorded on this handle's stream, waited on by another handle's
     std::vector<ChBatch*> batches;      // oisat_batch_create
     // task-graph plans of the last single-system factorizations on this handle (dense_dag.inc), keyed by what a plan depends on
+    const int* obs_perm = nullptr;      // oisat_set_obs_blocks: space-filling order of the observations of the next gain solves
+    int64_t obs_perm_m = 0;
     int dag_mode = -1;                  // oisat_set_task_graph: -1 = by size (and OISAT_DAG), 0 = recursion only, 1 = task graph wherever it applies
     DagSingle dag_cache[8];
     uint64_t dag_clock = 0;

@@ -38,6 +38,22 @@ def unit_vectors(lat_deg, lon_deg) -> np.ndarray:
     return np.ascontiguousarray(np.stack([np.cos(la) * np.cos(lo), np.cos(la) * np.sin(lo), np.sin(la)]))
 
 
+def morton_order(lat_deg, lon_deg) -> np.ndarray:
+    """int32 permutation that lists points along the Z-order curve of (latitude, longitude), 16 bits each: consecutive
+    entries are neighbours in space (what ``oisat_set_obs_blocks`` wants)."""
+    def spread(v):                                               # 16 bits -> every other bit of 32
+        v = v.astype(np.uint32)
+        v = (v | (v << 8)) & np.uint32(0x00FF00FF)
+        v = (v | (v << 4)) & np.uint32(0x0F0F0F0F)
+        v = (v | (v << 2)) & np.uint32(0x33333333)
+        v = (v | (v << 1)) & np.uint32(0x55555555)
+        return v
+    la = np.clip((np.asarray(lat_deg, dtype=np.float64) + 90.0) / 180.0 * 65535.0, 0, 65535)
+    lo = np.clip((np.mod(np.asarray(lon_deg, dtype=np.float64) + 180.0, 360.0)) / 360.0 * 65535.0, 0, 65535)
+    code = (spread(la.astype(np.uint32)) << np.uint32(1)) | spread(lo.astype(np.uint32))
+    return np.argsort(code, kind="stable").astype(np.int32)
+
+
 def decay_constant(L_km: float) -> float:
     """g in C = exp(-g * chord^2) for a correlation length L (km)."""
     return 0.5 * (EARTH_RADIUS_KM / float(L_km)) ** 2
@@ -109,6 +125,10 @@ class DenseAnalysis:
         if batched:
             self.state = c.alloc(256).shared_with_other_streams()
             c.check(c.lib.oisat_memset(c.h, self.state.ptr, 0, 256))
+        # the observations along a space-filling curve (compact blocks of rows for the float64 residual)
+        self.perm = c.alloc(self.max_obs * 4)
+        if batched:
+            self.perm.shared_with_other_streams()
         self.m = 0
         self._direct_innovation = False
         # every internal workspace of the solve is sized here, so that run() never allocates (include/oisat.h)
@@ -131,14 +151,14 @@ class DenseAnalysis:
         c = self.ctx
         self.m = m
         self.mp = -(-m // NB) * NB
-        o = self._sort_by_latitude(obs_lat)
+        o = self._sort_by_latitude(obs_lat, obs_lon)
         c.upload_into(self.oxyz.ptr, unit_vectors(np.ravel(obs_lat)[o], np.ravel(obs_lon)[o]))
         c.upload_into(self.osig.ptr, np.ravel(obs_sigma_b)[o], dtype=np.float64)
         c.upload_into(self.ovar.ptr, np.ravel(obs_var)[o], dtype=np.float64)
         c.upload_into(self.d.ptr, np.ravel(innovation)[o], dtype=np.float64)
         self._direct_innovation = True
 
-    def _sort_by_latitude(self, obs_lat):
+    def _sort_by_latitude(self, obs_lat, obs_lon):
         """Observations live on the device in ascending-latitude order: the pairs (cell, observation) and
         (observation, observation) whose correlation is above 2^-64 are then contiguous index ranges, which is what the
         latitude windows of ``oisat_apply_increment`` / ``oisat_cov_residual`` skip by.  Per-observation results
@@ -146,6 +166,11 @@ class DenseAnalysis:
         lat = np.ravel(np.asarray(obs_lat, dtype=np.float64))
         self._order = np.argsort(lat, kind="stable")
         self.ctx.upload_into(self.olat.ptr, lat[self._order], dtype=np.float64)
+        # ... and the float64 residual takes its blocks of 64 rows along a space-filling curve through them (Morton order of
+        # latitude x longitude, as a permutation of the latitude order): neighbours in space, a small bounding sphere
+        # (``oisat_set_obs_blocks``)
+        lon = np.ravel(np.asarray(obs_lon, dtype=np.float64))[self._order]
+        self.ctx.upload_into(self.perm.ptr, morton_order(lat[self._order], lon))
         return self._order
 
     def _unsort(self, per_obs):
@@ -161,7 +186,7 @@ class DenseAnalysis:
         c = self.ctx
         self.m = m
         self.mp = -(-m // NB) * NB
-        o = self._sort_by_latitude(obs_lat)
+        o = self._sort_by_latitude(obs_lat, obs_lon)
         cell = np.ascontiguousarray(np.ravel(obs_cell)[o], dtype=np.int64)
         c.upload_into(self.oxyz.ptr, unit_vectors(np.ravel(obs_lat)[o], np.ravel(obs_lon)[o]))
         c.upload_into(self.osig.ptr, self._gsig_host[cell], dtype=np.float64)
@@ -185,6 +210,7 @@ class DenseAnalysis:
         info = C.c_int(0)
         c.check(lib.oisat_potrf(h, self.S.ptr, m, ld, C.byref(info) if check_pd else None))
         resid = (C.c_double * (refine + 1))() if want_resid else None
+        c.check(lib.oisat_set_obs_blocks(h, self.perm.ptr, m))                                  # per run: handles are shared
         c.check(lib.oisat_gain_solve(h, self.S.ptr, self.oxyz.ptr, self.osig.ptr, self.ovar.ptr, m, ld, g, self.d.ptr,
                                      int(refine), self.z.ptr, resid, self.olat.ptr))
         c.check(lib.oisat_apply_increment_grid(h, self.code, self.gxyz.ptr, self.gsig.ptr, self._ny, self._nx, self.oxyz.ptr,
@@ -209,6 +235,7 @@ class DenseAnalysis:
         xb, xa, inc = self.xb_ptr, self.out_ptr, self.out_ptr + self.n * item
         c.check(lib.oisat_set_refine_tol(h, REFINE_TOL if tol is None else float(tol)))
         c.check(lib.oisat_factor_adopt(h, self.S.ptr, m, ld, self.tinv.ptr))
+        c.check(lib.oisat_set_obs_blocks(h, self.perm.ptr, m))
         c.check(lib.oisat_gain_solve(h, self.S.ptr, self.oxyz.ptr, self.osig.ptr, self.ovar.ptr, m, ld, g, self.d.ptr,
                                      int(refine), self.z.ptr, None, self.olat.ptr))
         c.check(lib.oisat_apply_increment_grid(h, self.code, self.gxyz.ptr, self.gsig.ptr, self._ny, self._nx, self.oxyz.ptr,
@@ -376,7 +403,8 @@ class BatchedFactor:
                     arr([p.work.ptr for p in g]), arr([p.state.ptr for p in g]), arr([p.gxyz.ptr for p in g]),
                     arr([p.gsig.ptr for p in g]), arr([p.glat.ptr for p in g]), (C.c_int64 * n)(*[p.n for p in g]),
                     arr([p.xb_ptr for p in g]), arr([p.out_ptr for p in g]), arr([p.out_ptr + p.n * item for p in g])))
-                ctx.check(ctx.lib.oisat_batch_set_grid(ctx.h, bid.value, n, (C.c_int64 * n)(*[p._nx for p in g])))
+                ctx.check(ctx.lib.oisat_batch_set_grid(ctx.h, bid.value, n, (C.c_int64 * n)(*[p._nx for p in g]),
+                                                       arr([p.perm.ptr for p in g])))
         self.group_of = {id(p): gi for gi, g in enumerate(self.groups) for p in g}
         self._threads = None
         # measured, one box (1 month of 720x1440 / 1e5 obs; a rank's eighth of 12 months; all 12 months):

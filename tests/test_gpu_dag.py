@@ -255,3 +255,40 @@ def test_increment_by_patches_equals_the_increment_by_runs(ctx, shape, m):
     w = ctx.download(osig.ptr, (m,), np.float64) * ctx.download(z.ptr, (m,), np.float64)
     ref = ctx.download(gsig.ptr, (n,), np.float64)[sel] * (np.exp(-g * d2) @ w)
     assert np.abs(inc1[sel] - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-30)
+
+
+@pytest.mark.parametrize("m,region", [(900, "box"), (3000, "cap"), (5000, "globe")])
+def test_residual_on_compact_blocks_equals_the_residual_by_latitude_rows(ctx, m, region):
+    """oisat_cov_residual with blocks of rows taken along the Morton curve (oisat_set_obs_blocks: bounding sphere, distance
+    cull of the latitude window's observations) against the plain form (64 consecutive latitudes per block) and against the
+    float64 contraction: the same terms per row in the same order up to terms below 2^-64 of a term."""
+    lib = ctx.lib
+    rng = np.random.default_rng(m)
+    if region == "box":
+        lat, lon = rng.uniform(-28.0, 33.0, m), rng.uniform(92.0, 168.0, m)
+    elif region == "cap":
+        lat, lon = rng.uniform(52.0, 90.0, m), rng.uniform(-180.0, 180.0, m)
+    else:
+        lat, lon = np.degrees(np.arcsin(rng.uniform(-1.0, 1.0, m))), rng.uniform(-180.0, 180.0, m)
+    o = np.argsort(lat, kind="stable")
+    lat, lon = lat[o], lon[o]
+    po = dense.unit_vectors(lat, lon)
+    oxyz = ctx.upload(po)
+    sig, var = rng.uniform(0.5, 1.5, m), rng.uniform(0.1, 0.3, m)
+    zz, dd = rng.normal(size=m), rng.normal(size=m)
+    osig, ovar, z, d = ctx.upload(sig), ctx.upload(var), ctx.upload(zz), ctx.upload(dd)
+    olat = ctx.upload(lat.astype(np.float64))
+    perm = ctx.upload(dense.morton_order(lat, lon))
+    g = dense.decay_constant(300.0)
+    outs = []
+    for blocks in (False, True):
+        r = ctx.alloc(m * 8)
+        ctx.check(lib.oisat_set_obs_blocks(ctx.h, perm.ptr if blocks else None, m if blocks else 0))
+        ctx.check(lib.oisat_cov_residual(ctx.h, oxyz.ptr, osig.ptr, ovar.ptr, m, g, d.ptr, z.ptr, r.ptr, olat.ptr))
+        outs.append(ctx.download(r.ptr, (m,), np.float64))
+    ctx.check(lib.oisat_set_obs_blocks(ctx.h, None, 0))
+    d2 = ((po[:, :, None] - po[:, None, :]) ** 2).sum(axis=0)
+    ref = dd - (sig * ((np.exp(-g * d2) * sig[None, :]) @ zz) + var * zz)
+    scale = np.abs(ref).max()
+    assert np.abs(outs[1] - outs[0]).max() <= 1e-12 * scale
+    assert np.abs(outs[1] - ref).max() <= 1e-11 * scale
