@@ -364,6 +364,14 @@ int oisat_posterior_error(oisat_ctx* h, const float* L, int64_t m, int64_t ld, c
 int oisat_gain_diag(oisat_ctx* h, const float* L, int64_t m, int64_t ld, const double* ovar, int64_t chunk_rows,
                     double* ak_out);
 
+/* The ticket list of a task-graph launch over nsys systems of block_rows[s] block rows (largest first), as the library would
+ * build it -- host only, no device: int32 quadruples (kind, system, i, j) with kind 0 = chain of `system` (i = first row of its
+ * trace stamps), 1 = tile task T(i, j), 2 = SUB(j) (tile (j+1, j)), 3 = PRE(j) (tile (j, j)), 4 = chain server of systems
+ * system .. system + i - 1.  wave <= 0 / serve < 0: the defaults (OISAT_DAG_WAVE, OISAT_DAG_SERVE).  capacity = 0 just
+ * counts.  For tests of the scheduling rule (every input of a task carries a lower ticket, or is its system's chain). */
+int oisat_dag_task_order(int nsys, const int32_t* block_rows, int wave, int serve, int32_t* tasks_out, int64_t capacity,
+                         int64_t* ntasks_out, int32_t* reserve_out);
+
 /* Schedule of the factorizations this handle runs from now on (oisat_potrf, batches made by oisat_batch_create): 1 = the
  * task graph (ONE persistent launch of left-looking tile tasks, csrc/dense_dag.inc) wherever it applies, 0 = the recursion
  * (one launch per node, lock-step over a batch), -1 (default) = by size: the task graph from three block rows up, unless the

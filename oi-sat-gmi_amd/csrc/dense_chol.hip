@@ -2158,6 +2158,20 @@ static inline bool dag_wanted(const oisat_ctx* h, int64_t max_blocks, int nsys, 
 
 void oisat_dag_plan_release(void* plan) { dag_plan_free((DagPlan*)plan); }
 
+extern "C" int oisat_dag_task_order(int nsys, const int32_t* block_rows, int wave, int serve, int32_t* tasks_out, int64_t capacity,
+                                    int64_t* ntasks_out, int32_t* reserve_out) {
+    ARG_CHECK(nsys > 0 && block_rows && ntasks_out && (tasks_out || capacity == 0));
+    std::vector<int> nb_of(block_rows, block_rows + nsys);
+    for (int s = 0; s < nsys; ++s) ARG_CHECK(nb_of[s] >= 1 && (s == 0 || nb_of[s] <= nb_of[s - 1]));
+    DagOrder order;
+    dag_task_order(nb_of, wave, serve, order);
+    *ntasks_out = (int64_t)order.tasks.size();
+    if (reserve_out) *reserve_out = order.reserve_chains;
+    if ((int64_t)order.tasks.size() > capacity) return capacity == 0 ? OISAT_OK : OISAT_EINVAL;
+    memcpy(tasks_out, order.tasks.data(), sizeof(int4) * order.tasks.size());
+    return OISAT_OK;
+}
+
 extern "C" int oisat_set_refine_tol(oisat_ctx* h, double tol) {
     ARG_CHECK(h != nullptr && tol >= 0.0 && tol < 1.0);
     h->refine_tol = tol;

@@ -1,8 +1,10 @@
 """Host-side logic of the drop-in package that needs no GPU."""
 import dataclasses
 import datetime
+import os
 
 import numpy as np
+import pytest
 
 from oisatgmi import config as cfg
 from oisatgmi import synthetic as syn
@@ -173,3 +175,64 @@ def test_tile_partition_polar_caps_and_halo():
     inside = (olat >= la0) & (olat <= la1) & (olon >= lo0) & (olon <= lo1)
     assert np.isin(np.flatnonzero(inside), t["obs"]).all()
     assert (olat[t["obs"]] >= la0 - h - 1e-9).all() and (olat[t["obs"]] <= la1 + h + 1e-9).all()
+
+
+# ------------------------------------------------------------------------------------------------
+# task-graph factorization: the ticket order (csrc/dense_dag.inc), checked on the host
+# ------------------------------------------------------------------------------------------------
+def _dag_order(block_rows, wave=0, serve=-1):
+    import ctypes as C
+    from oisatgmi import _hip
+    if not os.path.exists(_hip.library_path()):
+        import __graft_entry__ as g
+        g.build()
+    lib = C.CDLL(_hip.library_path())
+    lib.oisat_dag_task_order.restype = C.c_int
+    lib.oisat_dag_task_order.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int)]
+    nb = np.asarray(block_rows, dtype=np.int32)
+    n, res = C.c_int64(0), C.c_int(0)
+    assert lib.oisat_dag_task_order(len(nb), nb.ctypes.data, wave, serve, None, 0, C.byref(n), C.byref(res)) == 0
+    out = np.zeros((n.value, 4), dtype=np.int32)
+    assert lib.oisat_dag_task_order(len(nb), nb.ctypes.data, wave, serve, out.ctypes.data, n.value, C.byref(n), C.byref(res)) == 0
+    return out, res.value
+
+
+@pytest.mark.parametrize("block_rows,wave,serve", [([79], 0, -1), (sorted([137, 137] + [48, 47, 45, 44, 40, 33, 31] * 6, reverse=True), 8, 0),
+                                                   ([17, 12, 11, 8, 7, 5, 3, 3, 2, 1, 1], 2, 0), ([20, 9, 9, 8, 8, 7, 3, 2, 1], 5, 3)])
+def test_task_graph_ticket_order_is_topological_and_complete(block_rows, wave, serve):
+    """Every tile of every system is owned by exactly one task, and every input of a task carries a LOWER ticket or is a step of
+    its system's chain, whose own ticket is lower -- the property that lets the launch drain with any number of resident
+    workgroups (csrc/dense_dag.inc).  Inputs of a task on tile (i, j) of system s: the final blocks L(i, k), L(j, k), k < j
+    (k < j - 1 for PRE), each produced by the tile task T(., k) of that row -- or by the chain for the sub-diagonal tile -- and
+    the diagonal block j (chain)."""
+    tasks, reserve = _dag_order(block_rows, wave, serve)
+    ticket = {}
+    chain_ticket = {}
+    for t, (kind, s, i, j) in enumerate(tasks.tolist()):
+        if kind == 0:
+            assert s not in chain_ticket
+            chain_ticket[s] = t
+        elif kind == 4:
+            for q in range(s, s + i):
+                assert q not in chain_ticket
+                chain_ticket[q] = t
+        else:
+            assert (s, i, j) not in ticket
+            ticket[(s, i, j)] = (t, kind)
+    assert sorted(chain_ticket) == list(range(len(block_rows)))
+    for s, nb in enumerate(block_rows):
+        owned = {(i, j) for (q, i, j) in ticket if q == s}
+        expect = {(i, j) for j in range(nb) for i in range(j + 2, nb)} | {(j + 1, j) for j in range(1, nb - 1)} | {(j, j) for j in range(2, nb)}
+        assert owned == expect, s
+        for (q, i, j), (t, kind) in ticket.items():
+            if q != s:
+                continue
+            assert chain_ticket[s] < t
+            assert kind == (3 if i == j else 2 if i == j + 1 else 1)
+            for k in range(j - 1 if kind == 3 else j):          # producers of L(i, k) and L(j, k)
+                for r in {i, j}:
+                    if r >= k + 2:
+                        assert ticket[(s, r, k)][0] < t, (s, i, j, r, k)       # a tile task of a lower column
+                    # r == k + 1: the chain's panel tile; r == k cannot happen (k < j <= i)
+    # the chains that get a CU to themselves hold the first tickets
+    assert all(tasks[t][0] == 0 for t in range(reserve))
