@@ -2498,6 +2498,10 @@ extern "C" int oisat_batch_create(oisat_ctx* h, int nmat, float* const* S, const
     }
     if (dag_wanted(h, bt->max_mpb, nmat, h->cu_count)) {
         bt->dag = dag_plan_create(bt->table, h->stream);
+        if (bt->dag && hipStreamSynchronize(h->stream) != hipSuccess) {       // (the plan's words are zero before any stream can launch it)
+            oisat_dag_plan_release(bt->dag);
+            bt->dag = nullptr;
+        }
         if (!bt->dag) {
             (void)hipFree(bt->cum_dev);
             (void)hipFree(bt->table_dev);
