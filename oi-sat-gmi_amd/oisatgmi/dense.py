@@ -332,6 +332,7 @@ class BatchedFactor:
     def __init__(self, device: int, plans, ratio: float = 0.5):
         groups = []
         order = sorted((p for p in plans if p is not None), key=lambda p: -p.m)
+        every = list(order)
         # Task-graph factorization (csrc/dense_dag.inc; OISAT_DAG=0 turns it off): ONE persistent launch factors systems of
         # any mix of sizes -- tiles and polar caps together, every system's chain on a workgroup of its own, the tile tasks of
         # all systems drawn from one list -- so the groups are simply runs of at most OISAT_DAG_GROUP systems (default 96;
@@ -361,7 +362,7 @@ class BatchedFactor:
         # OISAT_BATCH_SOLVE=1 (default): the gain solves and increments of a group run in lock-step on the group's stream right
         # behind its factorization (oisat_batch_solve); 0: round 2's form -- the host waits for the group and enqueues every
         # plan's solve on its lane
-        self.batched_solve = os.environ.get("OISAT_BATCH_SOLVE", "1") != "0" and all(p.work is not None for p in order)
+        self.batched_solve = os.environ.get("OISAT_BATCH_SOLVE", "1") != "0" and all(p.work is not None for p in every)
         self.order = os.environ.get("OISAT_BATCH_ORDER", "largest")
         self.groups = groups if self.order == "largest" else groups[::-1]
         # schedule (OISAT_BATCH_SCHEDULE): "overlap" (default) -- one stream per group, all groups side by side;
