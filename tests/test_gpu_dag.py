@@ -73,7 +73,7 @@ def test_task_graph_factor_against_the_matrix_and_the_recursion(ctx, m):
 def test_task_graph_is_bitwise_repeatable(ctx):
     """A tile's products are accumulated in column order whatever the moment its inputs arrive (the K-loop is cut into
     segments by availability, never reordered): two runs of the same system give the same bits, and so does a run whose
-    chain shares its CU (no reservation) and one with acquires after every poll (the debugging switch)."""
+    chain shares its CU (no reservation) and one without the consumers' acquires (producer-side L1 drops alone)."""
     m = 2500
     build, mp, keep = _system(ctx, m, 77)
     S = ctx.alloc(mp * mp * 4)
