@@ -355,3 +355,30 @@ def test_task_graph_under_concurrent_uneven_load_is_bitwise_stable(ctx):
         th.join()
     assert not bad, bad
     assert min(counts.values()) >= 50, counts
+
+
+def test_task_graph_time_out_drains_the_launch_and_is_reported(ctx):
+    """Fault injection (OISAT_DAG_FLAGS = 128 | 256: the chains stop announcing their diagonal blocks at block 3, polls give up
+    after 4 096 rounds): the waiting tile tasks time out, raise the launch's error word, every other workgroup sees it and
+    leaves -- the launch ends within milliseconds instead of hanging --, the time-out is reported through the status words
+    (oisat_solve_status), and the NEXT factorization on the same plan finds the progress words clean and is correct."""
+    lib = ctx.lib
+    m = 1500
+    build, mp, keep = _system(ctx, m, 4242)
+    S = ctx.alloc(mp * mp * 4)
+    good = _factor(ctx, build, S, m, mp, 1)
+    ctx.solve_status(clear=True)
+    os.environ["OISAT_DAG_FLAGS"] = str(128 | 256)
+    try:
+        build(S)
+        ctx.check(lib.oisat_set_task_graph(ctx.h, 1))
+        ctx.check(lib.oisat_potrf(ctx.h, S.ptr, m, mp, None))
+        ctx.sync()
+    finally:
+        del os.environ["OISAT_DAG_FLAGS"]
+    col, nblk, nto = ctx.solve_status(clear=True)
+    assert nto >= 1 and col == 0
+    again = _factor(ctx, build, S, m, mp, 1)
+    assert np.array_equal(np.tril(again), np.tril(good))
+    assert ctx.solve_status(clear=True) == (0, 0, 0)
+    ctx.check(lib.oisat_set_task_graph(ctx.h, -1))
