@@ -2285,7 +2285,7 @@ extern "C" int oisat_potrf(oisat_ctx* h, float* S, int64_t m, int64_t ld, int* i
 extern "C" int oisat_potrs(oisat_ctx* h, const float* L, int64_t m, int64_t ld, double* z_inout) {
     ARG_CHECK(h && L && z_inout && m > 0);
     ARG_CHECK(h->factor.S == L && h->factor.m == m && h->factor.ld == ld);     // must follow oisat_potrf of this matrix
-    double* w = (double*)oisat_ws(h, 5, sizeof(double) * 2 * h->factor.mp);
+    double* w = (double*)oisat_ws(h, 5, sizeof(double) * (2 + 8) * h->factor.mp);
     if (!w) return OISAT_ENOMEM;
     double* rhs = w;
     double* fwd = w + h->factor.mp;
@@ -2312,7 +2312,7 @@ extern "C" int oisat_gain_solve(oisat_ctx* h, const float* L, const double* oxyz
     ARG_CHECK(h->factor.S == L && h->factor.m == m && h->factor.ld == ld);
     const double tol = h->refine_tol;
     const int64_t mp = h->factor.mp;
-    double* w = (double*)oisat_ws(h, 5, sizeof(double) * 2 * mp);
+    double* w = (double*)oisat_ws(h, 5, sizeof(double) * (2 + 8) * mp);
     SolveState* st = solve_state(h);
     if (!w || !st) return OISAT_ENOMEM;
     double* rhs = w;
@@ -2435,7 +2435,7 @@ extern "C" int oisat_dense_reserve(oisat_ctx* h, int64_t max_obs, int64_t diag_c
     const int64_t mp = cdiv(max_obs, NB) * NB;
     if (!oisat_ws(h, 3, sizeof(float) * mp * NB)) return OISAT_ENOMEM;                  // inverted diagonal blocks
     if (int rc = status_ws(h, nullptr, nullptr)) return rc;                              // slots 4 and 7
-    if (!oisat_ws(h, 5, sizeof(double) * 2 * mp)) return OISAT_ENOMEM;                   // padded rhs + forward solution
+    if (!oisat_ws(h, 5, sizeof(double) * (2 + 8) * mp)) return OISAT_ENOMEM;                   // padded rhs + forward solution
     if (!solve_state(h)) return OISAT_ENOMEM;                                            // slot 9: convergence state of the gain solve
     size_t s6 = sizeof(double) * (max_obs + 16);                                         // refinement residual
     if (diag_chunk_rows > 0) {

@@ -10,6 +10,8 @@
 // (v_exp_f32 is quarter rate), not HBM-bound -- except cov_build, which writes S once (4 m^2 B).
 #include "oisat_common.h"
 
+#include <algorithm>
+
 namespace {
 
 constexpr float kLog2e = 1.4426950408889634f;
@@ -181,7 +183,10 @@ __global__ __launch_bounds__(256) void cov_residual_kernel(const double* __restr
                                                             const double* __restrict__ ovar, int64_t m, double g,
                                                             const double* __restrict__ d, const double* __restrict__ z,
                                                             double* __restrict__ r, const double* __restrict__ olat, double win_deg,
-                                                            const int* __restrict__ converged, const SolveMember* __restrict__ mem) {
+                                                            const int* __restrict__ converged, const SolveMember* __restrict__ mem,
+                                                            double* __restrict__ partial, int nsplit) {
+    // partial != nullptr (single system with fewer than two blocks of rows per CU): blockIdx.y = one of nsplit slices of the
+    // column range; the slice's sums go to partial[y][row] and resid_combine_kernel adds them in slice order
     if (BATCH) {                                                // batched: blockIdx.y = member, r = its padded right-hand side
         const SolveMember* mb = mem + blockIdx.y;
         m = mb->m;
@@ -210,6 +215,12 @@ __global__ __launch_bounds__(256) void cov_residual_kernel(const double* __restr
         j1 = lower_bound_lat(olat, m, olat[r1] + win_deg + 1e-9);
         j0 &= ~(int64_t)255;                                    // keep the chunking aligned: same summation order per row
     }
+    if (!BATCH && partial != nullptr) {                         // this slice of [j0, j1), in whole chunks of 256 columns
+        const int64_t chunks = (j1 - j0 + 255) >> 8, per = (chunks + nsplit - 1) / nsplit;
+        const int64_t a = j0 + (int64_t)blockIdx.y * per * 256, b = a + per * 256;
+        j0 = a < j1 ? a : j1;
+        j1 = b < j1 ? b : j1;
+    }
     double acc = 0.0;
     for (int64_t c0 = j0; c0 < j1; c0 += 256) {
         const int64_t c = c0 + t;
@@ -230,8 +241,22 @@ __global__ __launch_bounds__(256) void cov_residual_kernel(const double* __restr
     __syncthreads();
     if (ph == 0 && live) {
         const double s = ((part[0][lr] + part[1][lr]) + part[2][lr]) + part[3][lr];
-        r[row] = d[row] - (osig[row] * s + ovar[row] * z[row]);
+        if (!BATCH && partial != nullptr) partial[(int64_t)blockIdx.y * m + row] = s;
+        else r[row] = d[row] - (osig[row] * s + ovar[row] * z[row]);
     }
+}
+
+// r = d - (sig * sum of the column slices' sums, in slice order, + var * z): second half of the sliced residual
+__global__ __launch_bounds__(256) void resid_combine_kernel(const double* __restrict__ partial, int nsplit, int64_t m,
+                                                             const double* __restrict__ osig, const double* __restrict__ ovar,
+                                                             const double* __restrict__ d, const double* __restrict__ z,
+                                                             double* __restrict__ r, const int* __restrict__ converged) {
+    if (converged != nullptr && *converged != 0) return;
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= m) return;
+    double s = 0.0;
+    for (int y = 0; y < nsplit; ++y) s += partial[(int64_t)y * m + row];
+    r[row] = d[row] - (osig[row] * s + ovar[row] * z[row]);
 }
 
 // ---- the same residual on COMPACT blocks of rows (round 3) ------------------------------------------------------------
@@ -505,8 +530,27 @@ int oisat_cov_residual_if(oisat_ctx* h, const double* oxyz, const double* osig, 
                      d, z, r_out, olat_sorted, win, converged_dev, (const SolveMember*)nullptr, perm, cut_chord_of(g2));
         return OISAT_OK;
     }
-    OISAT_LAUNCH(h, "cov_residual", cov_residual_kernel<false>, dim3((unsigned)cdiv(m, 64)), dim3(256), 0, oxyz, osig, ovar, m, g, d,
-                 z, r_out, win < 180.0 ? olat_sorted : (const double*)nullptr, win, converged_dev, (const SolveMember*)nullptr);
+    // fewer than two blocks of 64 rows per CU (m < 32,768 on 256 CUs): the column range is cut into slices, a workgroup per
+    // (block of rows, slice), and a second launch adds the slices' sums in order -- 157 workgroups of a 10,000-observation
+    // system left 40 % of the CUs empty and the others with one workgroup each: 0.21 -> 0.09 ms per evaluation
+    const int64_t blocks = cdiv(m, 64), cus = h->cu_count > 0 ? h->cu_count : 256;
+    int nsplit = blocks < 2 * cus ? (int)std::min<int64_t>(8, cdiv(2 * cus, blocks)) : 1;
+    static const int forced = getenv("OISAT_RESID_SPLIT") ? atoi(getenv("OISAT_RESID_SPLIT")) : 0;
+    if (forced >= 1 && forced <= 8) nsplit = forced;
+    double* partial = nullptr;
+    if (nsplit > 1) {                                       // behind the solve's two work vectors (oisat_dense_reserve sizes the slot)
+        const int64_t mp = cdiv(m, 128) * 128;
+        double* w = (double*)oisat_ws(h, 5, sizeof(double) * (2 + 8) * mp);
+        if (!w) return OISAT_ENOMEM;
+        partial = w + 2 * mp;
+    }
+    OISAT_LAUNCH(h, "cov_residual", cov_residual_kernel<false>, dim3((unsigned)blocks, (unsigned)nsplit), dim3(256), 0, oxyz, osig, ovar, m,
+                 g, d, z, r_out, win < 180.0 ? olat_sorted : (const double*)nullptr, win, converged_dev, (const SolveMember*)nullptr,
+                 partial, nsplit);
+    if (nsplit > 1) {
+        OISAT_LAUNCH(h, "cov_residual", resid_combine_kernel, dim3((unsigned)cdiv(m, 256)), dim3(256), 0, (const double*)partial, nsplit, m,
+                     osig, ovar, d, z, r_out, converged_dev);
+    }
     return OISAT_OK;
 }
 
@@ -606,7 +650,7 @@ int oisat_cov_residual_batched(oisat_ctx* h, const SolveMember* mem_dev, const s
     OISAT_LAUNCH(h, "cov_residual", cov_residual_kernel<true>, dim3((unsigned)cdiv(max_m, 64), (unsigned)nmem), dim3(256), 0,
                  (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, (int64_t)0, g, (const double*)nullptr,
                  (const double*)nullptr, (double*)nullptr, win < 180.0 ? &dummy : (const double*)nullptr, win, (const int*)nullptr,
-                 mem_dev);
+                 mem_dev, (double*)nullptr, 1);
     return OISAT_OK;
 }
 
