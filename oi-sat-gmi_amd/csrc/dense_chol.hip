@@ -2149,7 +2149,11 @@ static inline bool dag_wanted(const oisat_ctx* h, int64_t max_blocks, int nsys, 
     const int kDagMinBlocks = getenv("OISAT_DAG_MIN_BLOCKS") ? atoi(getenv("OISAT_DAG_MIN_BLOCKS")) : 3;
     const int kDagMaxBlocks = getenv("OISAT_DAG_MAX_BLOCKS") ? atoi(getenv("OISAT_DAG_MAX_BLOCKS")) : 1 << 20;
     if (kDagMode == 0) return false;
-    if (nsys > (cu_count > 0 ? cu_count : 256) / 2) return false;      // every chain needs a running workgroup of its own
+    // every chain of a wave needs a running workgroup of its own, next to enough others to draw the wave's tile tasks: waves are
+    // eight systems, except the first (the systems with at least half the block rows of the largest), which the caller keeps
+    // small -- a batch of up to OISAT_DAG_MAX_SYSTEMS_LIB systems (default 1024) is taken, more keep the lock-step recursion
+    static const int max_sys = getenv("OISAT_DAG_MAX_SYSTEMS_LIB") ? atoi(getenv("OISAT_DAG_MAX_SYSTEMS_LIB")) : 1024;
+    if (nsys > max_sys) return false;
     if (kDagMode == 1) return max_blocks >= 2;
     return max_blocks >= kDagMinBlocks && max_blocks <= kDagMaxBlocks;
 }

@@ -334,17 +334,18 @@ class BatchedFactor:
         order = sorted((p for p in plans if p is not None), key=lambda p: -p.m)
         every = list(order)
         # Task-graph factorization (csrc/dense_dag.inc; OISAT_DAG=0 turns it off): ONE persistent launch factors systems of
-        # any mix of sizes -- tiles and polar caps together, every system's chain on a workgroup of its own, the tile tasks of
-        # all systems drawn from one list -- so the groups are simply runs of at most OISAT_DAG_GROUP systems (default 96;
-        # the library takes up to half the CU count) in order of size.  Without it: lock-step recursion, which wants groups
-        # of comparable block count.
-        # Batches of more than OISAT_DAG_MAX_SYSTEMS (default 128: twelve months = 600 units) keep the lock-step recursion: its
-        # two groups overlap each other's solves, which a sequence of persistent launches does not (measured: 0.69 vs 1.03 s).
+        # any mix of sizes -- tiles and polar caps together, the systems entering the launch in waves, every system's chain on
+        # a workgroup of its own, the tile tasks drawn from one list -- so a batch of up to OISAT_DAG_MAX_SYSTEMS systems
+        # (default 1024) is ONE group (OISAT_DAG_GROUP systems per launch at most).  Measured against the two lock-step groups
+        # of the recursion: a month's 50 systems 62 vs 66 ms, a rank's 75 / 150 / 300 units of config 4 0.091 / 0.177 / 0.352 vs
+        # 0.103 / 0.185 / 0.357 s, all 600 units 0.700 vs 0.706 s (what the one launch gains its fully exposed solve phase
+        # costs).  Several launches side by side are what must be avoided: every launch's chains are resident and its tile
+        # tasks starve (seven launches of 96: 1.03 s).
         self.dag = (os.environ.get("OISAT_DAG", "-1") != "0" and bool(order)
-                    and len(order) <= int(os.environ.get("OISAT_DAG_MAX_SYSTEMS", "128"))
+                    and len(order) <= int(os.environ.get("OISAT_DAG_MAX_SYSTEMS", "1024"))
                     and order[0].mp // NB <= int(os.environ.get("OISAT_DAG_MAX_BLOCKS", str(1 << 20))))
         if self.dag:
-            per = max(1, int(os.environ.get("OISAT_DAG_GROUP", "96")))
+            per = max(1, int(os.environ.get("OISAT_DAG_GROUP", "1024")))
             groups = [order[i:i + per] for i in range(0, len(order), per)]
             order = []
         cur = []
