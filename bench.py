@@ -75,6 +75,8 @@ def parse():
                     "every rank's shard of each world size alone (prints only that leg)")
     ap.add_argument("--backend", default="nccl", help="process-group backend; gloo only to rehearse N>1 on a 1-GPU box")
     ap.add_argument("--rehearse-on-device0", action="store_true", help="every rank uses GPU 0 (rehearsal only)")
+    ap.add_argument("--launcher-selftest", type=int, default=None, metavar="RC",
+                    help="CPU-only check of the --gpus N launch plumbing: no GPU work, rank RC %% N exits with code RC")
     return ap.parse_args()
 
 
@@ -610,13 +612,79 @@ def config4_leg(ctx, args, world, rank, local, lat2, lon2, sync, barrier):
     return out
 
 
+def launch_command(ngpus, argv, port):
+    """The command line `--gpus N` (N > 1) from a plain shell turns into: one rank per GPU under torch.distributed.run, this
+    same script and arguments (reference: one job per month, run/job_submitter_sbatch.py:45-68)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(ngpus)}", "--master-addr", "127.0.0.1",
+            "--master-port", str(int(port)), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(ngpus, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes -- before this process has
+    imported torch or made any HIP call (a process that has initialised the GPU must not be replaced or forked) -- pass
+    the arguments through, print exactly the one JSON line rank 0 prints, hand everything else to stderr, and return the
+    children's exit code (non-zero if any rank failed, or if no JSON line came back)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:                             # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL across processes needs it on this driver
+    env["OISAT_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = launch_command(ngpus, argv, port)
+    print("bench.py: launching %d ranks: %s" % (ngpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = []
+    for line in proc.stdout:                               # rank 0's JSON line is the only thing this script prints to stdout
+        text = line.strip()
+        if text.startswith("{") and text.endswith("}"):
+            lines.append(text)
+        elif text:
+            print(text, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if lines:
+        print(lines[-1], flush=True)
+    if rc == 0 and not lines:
+        print("bench.py: the ranks exited cleanly but printed no JSON line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
+def launcher_selftest(args, world, rank):
+    """CPU-only check of the launch plumbing (tests/test_host_logic_cpu.py): every rank joins a gloo group, the ranks are
+    counted with an all-reduce, rank 0 prints ONE JSON line, and rank `--launcher-selftest` % world exits with that code."""
+    import torch
+    import torch.distributed as dist
+    seen = 1
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        seen = int(t.item())
+    if rank == 0:
+        print(json.dumps({"launcher_selftest": True, "world_size": world, "n_ranks_seen_by_backend": seen, "gpus": args.gpus,
+                          "steps": args.steps, "warmup": args.warmup, "self_launched": os.environ.get("OISAT_BENCH_SELF_LAUNCHED") == "1"}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    code = args.launcher_selftest
+    return code if code and rank == code % world else 0
+
+
 def main():
     args = parse()
+    launched = "WORLD_SIZE" in os.environ
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if not launched and args.gpus > 1:                     # plain `python bench.py --gpus N`: this process only launches
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+    if launched and args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} under a launcher that started {world} rank(s): the two must agree")
+    if args.launcher_selftest is not None:
+        sys.exit(launcher_selftest(args, world, rank))
     if args.rehearse_on_device0:
         local = 0
     os.environ["OISAT_DEVICE"] = str(local)
@@ -635,8 +703,18 @@ def main():
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     sync = torch.cuda.synchronize
     barrier = dist.barrier if world > 1 else None
+    ranks_seen, devices_seen = 1, [local]
     if world > 1:
         torch.zeros(1, device="cuda").add_(1)            # make sure the device context exists before the collectives
+        # what the BACKEND sees, not what the launcher was asked for: ranks counted by an all-reduce over the data-path group,
+        # and which device every rank sits on (N distinct devices unless --rehearse-on-device0)
+        one = torch.ones(1, device="cuda", dtype=torch.float64) if args.backend != "gloo" else torch.ones(1, dtype=torch.float64)
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())
+        mine = torch.tensor([local], dtype=torch.int64, device="cuda" if args.backend != "gloo" else "cpu")
+        got = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(got, mine)
+        devices_seen = [int(g.item()) for g in got]
 
     ny, nx, nobs, L, swaths, refine = WORKLOADS[args.workload]
     if args.refine is not None:
@@ -720,6 +798,11 @@ def main():
                        "parallelism": "one month per GPU; RCCL broadcast of the grid, gather of the fields to rank 0"},
             "solve_tflops_end_to_end": world * flops / (elapsed / args.steps) / 1e12,
             "refinement_residuals": resid,
+            "n_ranks_seen_by_backend": ranks_seen,
+            "backend": {"name": dist.get_backend() if world > 1 else None, "world_size": dist.get_world_size() if world > 1 else 1,
+                        "device_of_rank": devices_seen, "self_launched": os.environ.get("OISAT_BENCH_SELF_LAUNCHED") == "1"},
+            "parity_anchor": "dense Gaussian-B path: no reference code exists (SURVEY 8 a-ext); oracle = float64 SciPy Cholesky of the "
+                             "same definition, reference-anchored only in the L -> 0 limit against OI() golden outputs (DESIGN section 2)",
         }
     if rank == 0 and world == 1:
         if not args.no_roofline:

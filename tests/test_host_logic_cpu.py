@@ -236,3 +236,38 @@ def test_task_graph_ticket_order_is_topological_and_complete(block_rows, wave, s
                     # r == k + 1: the chain's panel tile; r == k cannot happen (k < j <= i)
     # the chains that get a CU to themselves hold the first tickets
     assert all(tasks[t][0] == 0 for t in range(reserve))
+
+
+def _run_bench(*argv, env_extra=None):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], capture_output=True, text=True, env=env, timeout=600)
+
+
+def test_bench_launches_its_own_ranks_from_a_plain_shell():
+    """`python bench.py --gpus N` with no launcher around it: N child ranks under torch.distributed.run,
+    arguments passed through, exactly ONE JSON line on stdout, the ranks counted by the backend itself."""
+    import json
+    import bench
+    cmd = bench.launch_command(4, ["--gpus", "4", "--steps", "9"], 2345)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "2345"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "9"] and cmd[-5].endswith("bench.py")
+    r = _run_bench("--gpus", "2", "--steps", "7", "--warmup", "2", "--launcher-selftest", "0")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line == {"launcher_selftest": True, "world_size": 2, "n_ranks_seen_by_backend": 2, "gpus": 2, "steps": 7, "warmup": 2,
+                    "self_launched": True}
+
+
+def test_bench_launcher_propagates_a_failing_rank_and_refuses_a_mismatched_launch():
+    r = _run_bench("--gpus", "2", "--launcher-selftest", "3")           # rank 3 % 2 = 1 exits with 3
+    assert r.returncode != 0
+    # under a launcher that started another number of ranks than --gpus says: refused before anything touches a GPU
+    r = _run_bench("--gpus", "2", "--launcher-selftest", "0", env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "must agree" in (r.stderr + r.stdout)
