@@ -343,7 +343,9 @@ int oisat_apply_increment_grid(oisat_ctx* h, int dtype, const double* gxyz, cons
  * residual of the gain solves that follow on this handle for systems of exactly m observations (oisat_gain_solve,
  * oisat_cov_residual) then takes its blocks of 64 rows from this list: a block has a small bounding sphere, and of the
  * latitude window's observations only those within the covariance's reach (2^-64) of it are visited -- the residual's rows
- * are otherwise 64 consecutive LATITUDES, all around the globe.  Same terms per row in the same order.  NULL / m = 0 clears. */
+ * are otherwise 64 consecutive LATITUDES, all around the globe.  Same terms per row in the same order.  NULL / m = 0 clears.
+ * ONE-SHOT: the next oisat_gain_solve / oisat_cov_residual call on the handle takes the list (if its m matches) and the handle
+ * forgets it, whatever that call returns -- perm must stay valid until that call's work has run, and is never read after. */
 int oisat_set_obs_blocks(oisat_ctx* h, const int32_t* perm, int64_t m);
 
 /* X <- X L^-T for nrows (multiple of 128) extra rows, X: dev float[nrows][ldx], ldx >= roundup(m,128).
@@ -366,11 +368,14 @@ int oisat_gain_diag(oisat_ctx* h, const float* L, int64_t m, int64_t ld, const d
 
 /* The ticket list of a task-graph launch over nsys systems of block_rows[s] block rows (largest first), as the library would
  * build it -- host only, no device: int32 quadruples (kind, system, i, j) with kind 0 = chain of `system` (i = first row of its
- * trace stamps), 1 = tile task T(i, j), 2 = SUB(j) (tile (j+1, j)), 3 = PRE(j) (tile (j, j)), 4 = chain server of systems
- * system .. system + i - 1.  wave <= 0 / serve < 0: the defaults (OISAT_DAG_WAVE, OISAT_DAG_SERVE).  capacity = 0 just
- * counts.  For tests of the scheduling rule (every input of a task carries a lower ticket, or is its system's chain). */
-int oisat_dag_task_order(int nsys, const int32_t* block_rows, int wave, int serve, int32_t* tasks_out, int64_t capacity,
-                         int64_t* ntasks_out, int32_t* reserve_out);
+ * trace stamps), 1 = tile task T(i, j), 2 = SUB(j) (tile (j+1, j)), 3 = PRE(j) (tile (j, j)).  wave <= 0: the default (eight
+ * systems per wave behind wave 0).  capacity = 0 just counts.  max_wave_chains_out (may be NULL): the chain tickets that can be
+ * resident at one time (the largest wave's and the next one's) -- a launch is only made when four times that many workgroups
+ * are resident (each chain holds one and waits for tasks that the others must draw); otherwise the factorization keeps the
+ * lock-step recursion.  For tests of the scheduling rule (every input of a task carries a lower ticket, or is its
+ * system's chain) and of that bound. */
+int oisat_dag_task_order(int nsys, const int32_t* block_rows, int wave, int32_t* tasks_out, int64_t capacity,
+                         int64_t* ntasks_out, int32_t* reserve_out, int32_t* max_wave_chains_out);
 
 /* Schedule of the factorizations this handle runs from now on (oisat_potrf, batches made by oisat_batch_create): 1 = the
  * task graph (ONE persistent launch of left-looking tile tasks, csrc/dense_dag.inc) wherever it applies, 0 = the recursion
@@ -450,13 +455,26 @@ int oisat_comm_gather(oisat_ctx* h, const void* send_dev, size_t bytes, void* re
 int oisat_comm_destroy(oisat_ctx* h);
 
 /* Status of the dense solves enqueued on this handle since the last call with clear != 0 (synchronises the stream; one
- * 20-byte read-back).  oisat_potrf / oisat_gain_solve only report failures when given info_host / resid_host; an
- * unchecked (fully asynchronous) run records them here instead:
- *   first_notpd_col  1-based column of the first non-positive pivot of any factorization (0 = none),
- *   n_notpd_blocks   number of diagonal blocks that met one,
- *   trsv_timeouts    triangular-solve workgroups that gave up waiting for a predecessor (their part of z is a NaN
- *                    fill pattern).
- * Any of the three may be NULL.  A caller must see three zeros before it trusts z / the analysis fields. */
+ * 36-byte read-back).  oisat_potrf / oisat_gain_solve only report failures when given info_host / resid_host; an
+ * unchecked (fully asynchronous) run records them here instead.  out[0 .. nwords-1], nwords <= OISAT_STATUS_WORDS:
+ *   OISAT_STATUS_NOTPD_COL          1-based column of the first non-positive pivot of any factorization (0 = none)
+ *   OISAT_STATUS_NOTPD_BLOCKS       number of diagonal blocks that met one
+ *   OISAT_STATUS_TRSV_TIMEOUTS      triangular-solve workgroups that gave up waiting for a predecessor (their part of z is a
+ *                                   NaN fill pattern)
+ *   OISAT_STATUS_UNCONVERGED        gain solves (oisat_gain_solve, members of oisat_batch_solve / oisat_batch_analyse) that took
+ *                                   every one of their `refine` corrections and whose float64 residual |d - S z| was still above
+ *                                   tol |d| behind the last one (oisat_set_refine_tol; tol = 0 never counts): z is the best
+ *                                   iterate, NOT within the tolerance -- the exact gain of optimal_interpolation.py:27 is what
+ *                                   the 1e-5 bar is measured against, so a caller must not take such fields for converged ones
+ *   OISAT_STATUS_UNCONVERGED_MEMBER the caller's index (oisat_batch_create order) of the first such batch member; -1 = none,
+ *                                   or a single-system solve
+ *   OISAT_STATUS_DAG_TIMEOUTS       task-graph factorizations that ended on a time-out (bounded spins): incomplete factors
+ * A caller must see zeros in words 0-3 and 5 before it trusts z / the analysis fields. */
+enum { OISAT_STATUS_NOTPD_COL = 0, OISAT_STATUS_NOTPD_BLOCKS = 1, OISAT_STATUS_TRSV_TIMEOUTS = 2, OISAT_STATUS_UNCONVERGED = 3,
+       OISAT_STATUS_UNCONVERGED_MEMBER = 4, OISAT_STATUS_DAG_TIMEOUTS = 5, OISAT_STATUS_WORDS = 6 };
+int oisat_solve_status_ex(oisat_ctx* h, int32_t* out, int nwords, int clear);
+/* The round-2 form: three words.  (It clears all six, so trsv_timeouts here also counts unconverged solves and task-graph
+ * time-outs: three zeros still mean "trust the fields".)  Any of the three may be NULL. */
 int oisat_solve_status(oisat_ctx* h, int* first_notpd_col, int* n_notpd_blocks, int* trsv_timeouts, int clear);
 
 /* Pre-size every internal workspace of the dense path for analyses of up to max_obs observations (and, if

@@ -1309,6 +1309,8 @@ __global__ __launch_bounds__(256) void pad_identity_kernel(float* __restrict__ S
 constexpr int TLD = NB + 1;              // LDS tile row stride (odd: row- and column-walks are conflict-free)
 constexpr unsigned long long kTrsvEmpty = 0x7ff80bad7ff80badull;      // a quiet NaN with that payload, both halves equal
 
+constexpr int kInfoUnconverged = 4, kInfoUnconvergedMember = 5, kInfoDagTimeouts = 6;     // status words (status_ws below)
+
 struct TrsvCtl {                         // zero when a sweep starts: zeroed at allocation, then by the last workgroup of every sweep
     unsigned ticket;
     unsigned error;
@@ -1517,8 +1519,10 @@ __global__ __launch_bounds__(256) void solve_prep_kernel(const double* __restric
 }
 
 // |r_k|^2 (and |d|^2 at k = 0) in one block, fixed order; sets the convergence flag when |r_k| <= tol |d|
+// final: this is the check behind the LAST allowed correction -- a solve that is still above its tolerance here is counted in
+// the handle's status words (info[4], info[5]); tol2 = 0 ("run every round") never counts
 __global__ __launch_bounds__(1024) void resid_check_kernel(const double* __restrict__ r, const double* __restrict__ d, int64_t m, int k,
-                                                            double tol2, SolveState* __restrict__ st) {
+                                                            double tol2, SolveState* __restrict__ st, int final, int* __restrict__ info) {
     __shared__ double sr[1024], sd[1024];
     if (st->conv != 0) return;
     double a = 0.0, b = 0.0;
@@ -1541,6 +1545,7 @@ __global__ __launch_bounds__(1024) void resid_check_kernel(const double* __restr
         st->norm[k] = sr[0];
         st->computed = k + 1;
         if (sr[0] <= tol2 * st->dd) st->conv = 1;
+        else if (final && tol2 > 0.0) atomicAdd(&info[kInfoUnconverged], 1);
     }
 }
 
@@ -1996,8 +2001,12 @@ int potrf_lookahead(oisat_ctx* h, float* S, int64_t ld, int64_t nb, float* tinv,
 }
 
 // Status words of the dense solve, zeroed when first allocated and from then on only by oisat_solve_status(clear):
-//   slot 4: int info[4]   = { first non-positive pivot column of the CURRENT factorization (reset by oisat_potrf),
-//                             first such column since the last clear, number of failing diagonal blocks since then, - }
+//   slot 4: int info[8]   = { first non-positive pivot column of the CURRENT factorization (reset by oisat_potrf),
+//                             first such column since the last clear, number of failing diagonal blocks since then,
+//                             1 + table index of the batch member that met the current one,
+//                             [4] gain solves that used every refinement round and still ended above the tolerance,
+//                             [5] 1 + member index of the first of them (0: a single-system solve, or none),
+//                             [6] task-graph launches that ended on a time-out (their factor is incomplete), - }
 //   slot 7: [unsigned err_total (16 B): triangular-solve workgroups that gave up waiting, since the last clear
 //            | control block of sweep 0 | control block of sweep 1]
 constexpr size_t kCtlBytes = ((sizeof(TrsvCtl) + 15) / 16) * 16;
@@ -2031,7 +2040,8 @@ __global__ __launch_bounds__(256) void solve_prep_batched_kernel(const SolveMemb
     }
 }
 
-__global__ __launch_bounds__(1024) void resid_check_batched_kernel(const SolveMember* __restrict__ mem, int k, double tol2) {
+__global__ __launch_bounds__(1024) void resid_check_batched_kernel(const SolveMember* __restrict__ mem, int k, double tol2, int final,
+                                                                    int* __restrict__ info) {
     __shared__ double sr[1024], sd[1024];
     const SolveMember* mb = mem + blockIdx.x;
     SolveState* st = mb->st;
@@ -2059,6 +2069,10 @@ __global__ __launch_bounds__(1024) void resid_check_batched_kernel(const SolveMe
         st->norm[k] = sr[0];
         st->computed = k + 1;
         if (sr[0] <= tol2 * st->dd) st->conv = 1;
+        else if (final && tol2 > 0.0) {
+            atomicAdd(&info[kInfoUnconverged], 1);
+            atomicCAS(&info[kInfoUnconvergedMember], 0, mb->which + 1);
+        }
     }
 }
 
@@ -2138,39 +2152,32 @@ hipError_t dense_kernel_attributes() {
 
 #include "dense_dag.inc"
 
-// Which factorizations run as a task graph: systems of OISAT_DAG_MIN_BLOCKS .. OISAT_DAG_MAX_BLOCKS block rows (a single
-// system) / batches whose largest member has at most OISAT_DAG_MAX_BLOCKS; OISAT_DAG=0 turns it off, OISAT_DAG=1 forces it.
-// Measured against the recursion (factorization alone, TFLOP/s): 10,000 observations 91.9 vs 53.9, 20,000: 126 vs 94,
-// 30,000: 135 vs 115, 50,000: 138 vs 128, 100,000: 140.8 vs 137.4 -- the task graph wins at every size, so there is no
-// upper bound by default; below three block rows there is nothing to overlap.
-// (read at every call: a plan is made once per system / batch, and tests switch the schedule inside one process)
-static inline bool dag_wanted(const oisat_ctx* h, int64_t max_blocks, int nsys, int cu_count) {
-    const int kDagMode = h->dag_mode >= 0 ? h->dag_mode : (getenv("OISAT_DAG") ? atoi(getenv("OISAT_DAG")) : -1);
-    const int kDagMinBlocks = getenv("OISAT_DAG_MIN_BLOCKS") ? atoi(getenv("OISAT_DAG_MIN_BLOCKS")) : 3;
-    const int kDagMaxBlocks = getenv("OISAT_DAG_MAX_BLOCKS") ? atoi(getenv("OISAT_DAG_MAX_BLOCKS")) : 1 << 20;
-    if (kDagMode == 0) return false;
-    // every chain of a wave needs a running workgroup of its own, next to enough others to draw the wave's tile tasks: waves are
-    // eight systems, except the first (the systems with at least half the block rows of the largest), which the caller keeps
-    // small -- a batch of up to OISAT_DAG_MAX_SYSTEMS_LIB systems (default 1024) is taken, more keep the lock-step recursion
-    static const int max_sys = getenv("OISAT_DAG_MAX_SYSTEMS_LIB") ? atoi(getenv("OISAT_DAG_MAX_SYSTEMS_LIB")) : 1024;
-    if (nsys > max_sys) return false;
-    if (kDagMode == 1) return max_blocks >= 2;
-    return max_blocks >= kDagMinBlocks && max_blocks <= kDagMaxBlocks;
+// Which factorizations run as a task graph: every system / batch of at least three block rows (below that there is nothing to
+// overlap), unless the handle says otherwise (oisat_set_task_graph) or the environment does (OISAT_DAG=0 | 1: the parity tests
+// compare the two schedules inside one process, so it is read at every call).  Measured against the recursion
+// (factorization alone, TFLOP/s): 10,000 observations 91.9 vs 53.9, 20,000: 126 vs 94, 30,000: 135 vs 115, 50,000: 138 vs
+// 128, 100,000: 140.8 vs 137.4 -- the task graph wins at every size.  A batch of more than 1024 systems keeps the lock-step
+// recursion, and so does any launch whose chains would not leave room for the tasks they wait for (dag_fits).
+static inline bool dag_wanted(const oisat_ctx* h, int64_t max_blocks, int nsys) {
+    const int mode = h->dag_mode >= 0 ? h->dag_mode : (getenv("OISAT_DAG") ? atoi(getenv("OISAT_DAG")) : -1);
+    if (mode == 0 || nsys > 1024) return false;
+    return max_blocks >= (mode == 1 ? 2 : 3);
 }
 
 }  // namespace
 
 void oisat_dag_plan_release(void* plan) { dag_plan_free((DagPlan*)plan); }
 
-extern "C" int oisat_dag_task_order(int nsys, const int32_t* block_rows, int wave, int serve, int32_t* tasks_out, int64_t capacity,
-                                    int64_t* ntasks_out, int32_t* reserve_out) {
+extern "C" int oisat_dag_task_order(int nsys, const int32_t* block_rows, int wave, int32_t* tasks_out, int64_t capacity,
+                                    int64_t* ntasks_out, int32_t* reserve_out, int32_t* max_wave_chains_out) {
     ARG_CHECK(nsys > 0 && block_rows && ntasks_out && (tasks_out || capacity == 0));
     std::vector<int> nb_of(block_rows, block_rows + nsys);
     for (int s = 0; s < nsys; ++s) ARG_CHECK(nb_of[s] >= 1 && (s == 0 || nb_of[s] <= nb_of[s - 1]));
     DagOrder order;
-    dag_task_order(nb_of, wave, serve, order);
+    dag_task_order(nb_of, wave, order);
     *ntasks_out = (int64_t)order.tasks.size();
     if (reserve_out) *reserve_out = order.reserve_chains;
+    if (max_wave_chains_out) *max_wave_chains_out = order.max_wave_chains;
     if ((int64_t)order.tasks.size() > capacity) return capacity == 0 ? OISAT_OK : OISAT_EINVAL;
     memcpy(tasks_out, order.tasks.data(), sizeof(int4) * order.tasks.size());
     return OISAT_OK;
@@ -2234,7 +2241,7 @@ extern "C" int oisat_potrf(oisat_ctx* h, float* S, int64_t m, int64_t ld, int* i
         }
     }
     int rc;
-    if (!lookahead && !getenv("OISAT_POTRF") && dag_wanted(h, mpb, 1, h->cu_count)) {
+    if (!lookahead && !getenv("OISAT_POTRF") && dag_wanted(h, mpb, 1) && dag_fits(1, dag_slots(h))) {
         // the plan of this (S, tinv, ld, block rows) -- a handle keeps the last few (a lane that factors its tiles one after
         // the other in ONE shared buffer meets the same few sizes month after month)
         DagSingle* hit = nullptr;
@@ -2258,9 +2265,7 @@ extern "C" int oisat_potrf(oisat_ctx* h, float* S, int64_t m, int64_t ld, int* i
             hit = slot;
         }
         hit->stamp = ++h->dag_clock;
-        char* tbase = nullptr;
-        if (int rs = status_ws(h, nullptr, &tbase)) return rs;
-        rc = dag_launch(h, *(DagPlan*)hit->plan, info_dev, (unsigned*)tbase);
+        rc = dag_launch(h, *(DagPlan*)hit->plan, info_dev, (unsigned*)(info_dev + kInfoDagTimeouts));
     } else {
         rc = lookahead ? potrf_lookahead(h, S, ld, mpb, tinv, info_dev, pw) : potrf_rec(h, S, ld, mpb, 0, mpb, tinv, info_dev);
     }
@@ -2273,9 +2278,14 @@ extern "C" int oisat_potrf(oisat_ctx* h, float* S, int64_t m, int64_t ld, int* i
     if (info_host) {
         int* pin = (int*)oisat_pinned(h, 64);
         if (!pin) return OISAT_ENOMEM;
-        HIP_TRY(hipMemcpyAsync(pin, info_dev, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(pin, info_dev, 8 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
         *info_host = *pin;
+        if (pin[kInfoDagTimeouts] != 0) {                       // reported here, not again by oisat_solve_status
+            HIP_TRY(hipMemsetAsync(info_dev + kInfoDagTimeouts, 0, sizeof(int), h->stream));
+            oisat_set_error("potrf: the task-graph factorization timed out (a workgroup gave up waiting): the factor is incomplete");
+            return OISAT_EHIP;
+        }
         if (*pin != 0) {
             // reported to the caller right here: do not report it a second time through oisat_solve_status
             HIP_TRY(hipMemsetAsync(info_dev + 1, 0, 2 * sizeof(int), h->stream));
@@ -2299,7 +2309,9 @@ extern "C" int oisat_potrs(oisat_ctx* h, const float* L, int64_t m, int64_t ld, 
 }
 
 int oisat_cov_residual_if(oisat_ctx* h, const double* oxyz, const double* osig, const double* ovar, int64_t m, double g,
-                          const double* d, const double* z, double* r_out, const double* olat_sorted, const int* converged_dev);
+                          const double* d, const double* z, double* r_out, const double* olat_sorted, const int* converged_dev,
+                          const int* perm);
+const int* oisat_take_obs_perm(oisat_ctx* h, int64_t m);
 
 // z = S^-1 d through the fp32 factor as a preconditioner:  z <- M^-1 d;  repeat { r = d - S z (float64, S regenerated from
 // coordinates);  stop if |r| <= tol |d|;  z <- z + M^-1 r }  at most `refine` times.  tol = 1e-6 (oisat_set_refine_tol; env OISAT_REFINE_TOL at init): the
@@ -2312,7 +2324,9 @@ int oisat_cov_residual_if(oisat_ctx* h, const double* oxyz, const double* osig, 
 extern "C" int oisat_gain_solve(oisat_ctx* h, const float* L, const double* oxyz, const double* osig, const double* ovar, int64_t m,
                                 int64_t ld, double g, const double* d, int refine, double* z_out, double* resid_host,
                                 const double* olat_sorted) {
-    ARG_CHECK(h && L && oxyz && osig && ovar && d && z_out && m > 0 && refine >= 0 && refine <= 8);
+    ARG_CHECK(h != nullptr);
+    const int* perm = oisat_take_obs_perm(h, m);               // one-shot, whatever this call's outcome
+    ARG_CHECK(L && oxyz && osig && ovar && d && z_out && m > 0 && refine >= 0 && refine <= 8);
     ARG_CHECK(h->factor.S == L && h->factor.m == m && h->factor.ld == ld);
     const double tol = h->refine_tol;
     const int64_t mp = h->factor.mp;
@@ -2324,11 +2338,15 @@ extern "C" int oisat_gain_solve(oisat_ctx* h, const float* L, const double* oxyz
     OISAT_LAUNCH(h, "copy_pad", solve_prep_kernel, dim3(stream_grid(mp, 256)), dim3(256), 0, d, m, mp, rhs, fwd, st);
     int rc = trsv_solve(h, h->factor, rhs, fwd, nullptr, z_out, 0);
     if (rc) return rc;
-    const int rounds = resid_host ? refine + 1 : refine;        // reporting also wants the residual after the last correction
-    for (int it = 0; it < rounds; ++it) {
-        rc = oisat_cov_residual_if(h, oxyz, osig, ovar, m, g, d, z_out, rhs, olat_sorted, &st->conv);
+    // the residual is evaluated once more behind the last allowed correction: a converged solve skips it (no-op launches), one
+    // that is still above the tolerance there is recorded in the handle's status (oisat_solve_status_ex)
+    int* info_dev = nullptr;
+    if (int rs = status_ws(h, &info_dev, nullptr)) return rs;
+    for (int it = 0; it <= refine; ++it) {
+        rc = oisat_cov_residual_if(h, oxyz, osig, ovar, m, g, d, z_out, rhs, olat_sorted, &st->conv, perm);
         if (rc) return rc;
-        OISAT_LAUNCH(h, "resid_check", resid_check_kernel, dim3(1), dim3(1024), 0, (const double*)rhs, d, m, it, tol * tol, st);
+        OISAT_LAUNCH(h, "resid_check", resid_check_kernel, dim3(1), dim3(1024), 0, (const double*)rhs, d, m, it, tol * tol, st,
+                     it == refine ? 1 : 0, info_dev);
         if (it == refine) break;
         rc = trsv_solve(h, h->factor, rhs, fwd, st, z_out, 1);
         if (rc) return rc;
@@ -2414,23 +2432,36 @@ extern "C" int oisat_gain_diag(oisat_ctx* h, const float* L, int64_t m, int64_t 
     return OISAT_OK;
 }
 
-extern "C" int oisat_solve_status(oisat_ctx* h, int* first_notpd_col, int* n_notpd_blocks, int* trsv_timeouts, int clear) {
-    ARG_CHECK(h != nullptr);
+// words of oisat_solve_status_ex (include/oisat.h: OISAT_STATUS_*)
+extern "C" int oisat_solve_status_ex(oisat_ctx* h, int32_t* out, int nwords, int clear) {
+    ARG_CHECK(h != nullptr && (out != nullptr || nwords == 0) && nwords >= 0 && nwords <= OISAT_STATUS_WORDS);
     int* info = nullptr;
     char* base = nullptr;
     if (int rc = status_ws(h, &info, &base)) return rc;
     int* pin = (int*)oisat_pinned(h, 256);
     if (!pin) return OISAT_ENOMEM;
-    HIP_TRY(hipMemcpyAsync(pin, info, 4 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipMemcpyAsync(pin + 4, base, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(pin, info, 8 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(pin + 8, base, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     if (clear) {
         HIP_TRY(hipMemsetAsync(info + 1, 0, 2 * sizeof(int), h->stream));
+        HIP_TRY(hipMemsetAsync(info + kInfoUnconverged, 0, 3 * sizeof(int), h->stream));
         HIP_TRY(hipMemsetAsync(base, 0, 16, h->stream));
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
-    if (first_notpd_col) *first_notpd_col = pin[1];
-    if (n_notpd_blocks) *n_notpd_blocks = pin[2];
-    if (trsv_timeouts) *trsv_timeouts = pin[4];
+    const int32_t words[OISAT_STATUS_WORDS] = {pin[1], pin[2], pin[8], pin[kInfoUnconverged], pin[kInfoUnconvergedMember] - 1,
+                                               pin[kInfoDagTimeouts]};
+    for (int i = 0; i < nwords; ++i) out[i] = words[i];
+    return OISAT_OK;
+}
+
+extern "C" int oisat_solve_status(oisat_ctx* h, int* first_notpd_col, int* n_notpd_blocks, int* trsv_timeouts, int clear) {
+    int32_t w[OISAT_STATUS_WORDS];
+    // (kept for callers of the round-2 ABI: the three words it knows; a clear resets all six, so such a caller folds the
+    // others into the time-out count rather than lose them)
+    if (int rc = oisat_solve_status_ex(h, w, OISAT_STATUS_WORDS, clear)) return rc;
+    if (first_notpd_col) *first_notpd_col = w[OISAT_STATUS_NOTPD_COL];
+    if (n_notpd_blocks) *n_notpd_blocks = w[OISAT_STATUS_NOTPD_BLOCKS];
+    if (trsv_timeouts) *trsv_timeouts = w[OISAT_STATUS_TRSV_TIMEOUTS] + w[OISAT_STATUS_DAG_TIMEOUTS] + w[OISAT_STATUS_UNCONVERGED];
     return OISAT_OK;
 }
 
@@ -2500,7 +2531,15 @@ extern "C" int oisat_batch_create(oisat_ctx* h, int nmat, float* const* S, const
             return OISAT_ENOMEM;
         }
     }
-    if (dag_wanted(h, bt->max_mpb, nmat, h->cu_count)) {
+    bool want_dag = dag_wanted(h, bt->max_mpb, nmat);
+    if (want_dag) {                                          // would its chains crowd out the tasks they wait for?  (host-only check)
+        std::vector<int> nb_of(nmat);
+        for (int i = 0; i < nmat; ++i) nb_of[i] = bt->table[i].mpb;
+        DagOrder probe;
+        dag_task_order(nb_of, 0, probe);
+        want_dag = dag_fits(probe.max_wave_chains, dag_slots(h));        // no: the batch keeps the lock-step recursion
+    }
+    if (want_dag) {
         bt->dag = dag_plan_create(bt->table, h->stream);
         if (bt->dag && hipStreamSynchronize(h->stream) != hipSuccess) {       // (the plan's words are zero before any stream can launch it)
             oisat_dag_plan_release(bt->dag);
@@ -2564,6 +2603,7 @@ extern "C" int oisat_batch_set_solve(oisat_ctx* h, int batch_id, int nmat, const
         sm.z = z[c]; sm.rhs = work[c]; sm.fwd = work[c] + (int64_t)bm.mpb * NB; sm.st = (SolveState*)state[c];
         sm.gxyz = gxyz[c]; sm.gsig = gsig[c]; sm.glat = glat[c]; sm.n = n[c]; sm.xb = xb[c]; sm.xa = xa[c]; sm.inc = inc[c];
         sm.perm = nullptr;
+        sm.which = c;
         if (bm.m > bt->max_m) bt->max_m = bm.m;
         if (n[c] > bt->max_n) bt->max_n = n[c];
         if ((int64_t)bm.mpb * NB > bt->max_mp) bt->max_mp = (int64_t)bm.mpb * NB;
@@ -2639,10 +2679,14 @@ extern "C" int oisat_batch_solve(oisat_ctx* h, int batch_id, int dtype, double g
     };
     int rc = sweeps(1, 0);
     if (rc) return rc;
-    for (int it = 0; it < refine; ++it) {
+    int* info_dev = nullptr;
+    if (int rs = status_ws(h, &info_dev, nullptr)) return rs;
+    for (int it = 0; it <= refine; ++it) {                  // (the last evaluation only runs for members that are still above the tolerance)
         rc = oisat_cov_residual_batched(h, mem, bt.solve_host, bt.max_m, g);
         if (rc) return rc;
-        OISAT_LAUNCH(h, "resid_check", resid_check_batched_kernel, dim3((unsigned)nmem), dim3(1024), 0, mem, it, tol * tol);
+        OISAT_LAUNCH(h, "resid_check", resid_check_batched_kernel, dim3((unsigned)nmem), dim3(1024), 0, mem, it, tol * tol,
+                     it == refine ? 1 : 0, info_dev);
+        if (it == refine) break;
         rc = sweeps(0, 1);
         if (rc) return rc;
     }
@@ -2661,9 +2705,7 @@ extern "C" int oisat_batch_potrf(oisat_ctx* h, int batch_id, int* info_host) {
                  (const BatchMat*)bt.table_dev);
     int rc;
     if (bt.dag) {
-        char* tbase = nullptr;
-        if (int rs = status_ws(h, nullptr, &tbase)) return rs;
-        rc = dag_launch(h, *(DagPlan*)bt.dag, info_dev, (unsigned*)tbase);
+        rc = dag_launch(h, *(DagPlan*)bt.dag, info_dev, (unsigned*)(info_dev + kInfoDagTimeouts));
     } else {
         rc = potrf_rec_batched(h, bt, 0, bt.max_mpb, info_dev);
     }
@@ -2671,10 +2713,15 @@ extern "C" int oisat_batch_potrf(oisat_ctx* h, int batch_id, int* info_host) {
     if (info_host) {
         int* pin = (int*)oisat_pinned(h, 64);
         if (!pin) return OISAT_ENOMEM;
-        HIP_TRY(hipMemcpyAsync(pin, info_dev, 4 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(pin, info_dev, 8 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
         info_host[0] = pin[0];
         info_host[1] = pin[0] ? bt.order[pin[3] - 1] : -1;          // the caller's matrix index
+        if (pin[kInfoDagTimeouts] != 0) {
+            HIP_TRY(hipMemsetAsync(info_dev + kInfoDagTimeouts, 0, sizeof(int), h->stream));
+            oisat_set_error("batched potrf: the task-graph factorization timed out (a workgroup gave up waiting): the factors are incomplete");
+            return OISAT_EHIP;
+        }
         if (pin[0] != 0) {
             HIP_TRY(hipMemsetAsync(info_dev + 1, 0, 2 * sizeof(int), h->stream));
             oisat_set_error("batched potrf: matrix %d not positive definite at column %d", info_host[1], pin[0]);

@@ -518,13 +518,23 @@ static inline bool residual_blocks_pay(double g2) {
     return sqrt(64.0 / g2) <= 0.5;                              // chord on the unit sphere: 3 200 km
 }
 
-// perm (optional, device): the observations along a space-filling curve (oisat_set_obs_blocks) -> compact blocks of rows
+// The permutation handed over by oisat_set_obs_blocks is ONE-SHOT: the next gain solve / residual on the handle takes it
+// and the handle forgets it, so a buffer the caller frees or re-targets afterwards is never read again (a stale
+// pointer matched by m alone was an out-of-bounds gather waiting to happen).
+const int* oisat_take_obs_perm(oisat_ctx* h, int64_t m) {
+    const int* perm = h->obs_perm_m == m ? h->obs_perm : nullptr;
+    h->obs_perm = nullptr;
+    h->obs_perm_m = 0;
+    return perm;
+}
+
+// perm (optional, device): the observations along a space-filling curve (oisat_take_obs_perm) -> compact blocks of rows
 int oisat_cov_residual_if(oisat_ctx* h, const double* oxyz, const double* osig, const double* ovar, int64_t m, double g,
-                          const double* d, const double* z, double* r_out, const double* olat_sorted, const int* converged_dev) {
+                          const double* d, const double* z, double* r_out, const double* olat_sorted, const int* converged_dev,
+                          const int* perm) {
     ARG_CHECK(h && oxyz && osig && ovar && d && z && r_out && m > 0);
     const double g2 = g * (double)kLog2e;
     const double win = lat_window_deg(g2);
-    const int* perm = h->obs_perm_m == m ? h->obs_perm : nullptr;
     if (perm && olat_sorted && residual_blocks_pay(g2)) {
         OISAT_LAUNCH(h, "cov_residual", cov_residual_blocks_kernel<false>, dim3((unsigned)cdiv(m, 64)), dim3(256), 0, oxyz, osig, ovar, m, g,
                      d, z, r_out, olat_sorted, win, converged_dev, (const SolveMember*)nullptr, perm, cut_chord_of(g2));
@@ -563,7 +573,8 @@ extern "C" int oisat_set_obs_blocks(oisat_ctx* h, const int32_t* perm, int64_t m
 
 extern "C" int oisat_cov_residual(oisat_ctx* h, const double* oxyz, const double* osig, const double* ovar, int64_t m, double g,
                                   const double* d, const double* z, double* r_out, const double* olat_sorted) {
-    return oisat_cov_residual_if(h, oxyz, osig, ovar, m, g, d, z, r_out, olat_sorted, nullptr);
+    ARG_CHECK(h != nullptr);
+    return oisat_cov_residual_if(h, oxyz, osig, ovar, m, g, d, z, r_out, olat_sorted, nullptr, oisat_take_obs_perm(h, m));
 }
 
 // two cells per thread share every observation fetched from LDS; with too few cells to fill the GPU that way (a polar cap:

@@ -66,6 +66,7 @@ struct SolveMember {             // one system of a batched solve phase (device 
     void* xa;
     void* inc;
     const int* perm;             // its observations along a space-filling curve (compact residual blocks) or nullptr
+    int which;                   // the caller's index of this member (oisat_batch_set_solve order), reported by the status words
 };
 
 struct ChBatch {                 // matrices factored in lock-step by oisat_batch_potrf (sorted by block count, largest first)

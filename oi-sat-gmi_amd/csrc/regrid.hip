@@ -215,6 +215,8 @@ __device__ __forceinline__ unsigned tile_scan4(const unsigned v[4], unsigned ex[
 // Single-pass scan with decoupled look-back: block = one tile of 4096 counters (taken by ticket, so every predecessor has
 // started), publishes its tile total, sums the totals / prefixes of the tiles before it, publishes its inclusive prefix.
 // status[t]: bits 62-63 = 1 (tile total) | 2 (inclusive prefix), low 32 bits the value; status and ticket arrive zeroed.
+// ticket[1]: raised if a look-back ever gives up on a predecessor (bounded spin) -- the prefix is then wrong, and the host
+// fails the query instead of handing out indices built on it (nn_query_impl reads the word back).
 __global__ __launch_bounds__(1024) void nn_scan_lookback_kernel(const unsigned* __restrict__ counts, int64_t n, unsigned* __restrict__ start,
                                                                  unsigned* __restrict__ cursor, unsigned long long* __restrict__ status,
                                                                  unsigned* __restrict__ ticket) {
@@ -238,7 +240,10 @@ __global__ __launch_bounds__(1024) void nn_scan_lookback_kernel(const unsigned* 
                 unsigned spins = 0;
                 while (((st = __hip_atomic_load(&status[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 62) == 0ull) {
                     __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1u << 24)) break;                    // bounded: a predecessor always publishes (it holds a lower ticket)
+                    if (++spins > (1u << 24)) {                         // bounded: a predecessor always publishes (it holds a lower ticket);
+                        __hip_atomic_store(&ticket[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // if it ever does not: say so
+                        break;
+                    }
                 }
                 prev += (unsigned)(st & 0xffffffffull);
                 if ((st >> 62) == 2ull) break;
@@ -785,7 +790,8 @@ __global__ __launch_bounds__(256) void minmax_kernel(const double* __restrict__ 
 // Hash the points into uniform cells of edge `cell` (coarsened if that would need too many cells).
 // On return start[c]..start[c+1] index `sorted` (point ids of cell c); both live in workspace slot 2.
 static int build_hash(oisat_ctx* h, const double* plon, const double* plat, int64_t P, double cell, HashGrid* g_out,
-                      const unsigned** start_out, const int32_t** sorted_out, const double2** sxy_out = nullptr) {
+                      const unsigned** start_out, const int32_t** sorted_out, const double2** sxy_out = nullptr,
+                      const unsigned** scan_error_out = nullptr) {
     // 1. bounding box of the points
     const int mm_blocks = 64;
     double* mm_dev = (double*)oisat_ws(h, 1, sizeof(double) * 4 * mm_blocks);
@@ -842,7 +848,15 @@ static int build_hash(oisat_ctx* h, const double* plon, const double* plat, int6
     *start_out = start;
     *sorted_out = sorted;
     if (sxy_out) *sxy_out = sxy;
+    if (scan_error_out) *scan_error_out = ticket + 1;
     return OISAT_OK;
+}
+
+// after the caller's synchronisation: did the hash's counter scan give up on a predecessor (nn_scan_lookback_kernel)?
+static int scan_error_check(const unsigned* host_word) {
+    if (*host_word == 0u) return OISAT_OK;
+    oisat_set_error("nearest-neighbour hash: the counter scan gave up waiting for a predecessor tile (bounded spin): no indices handed out");
+    return OISAT_EHIP;
 }
 
 static int nn_query_impl(oisat_ctx* h, const double* plon, const double* plat, int64_t P, const double* tlon, const double* tlat,
@@ -854,26 +868,27 @@ static int nn_query_impl(oisat_ctx* h, const double* plon, const double* plat, i
     const unsigned* start;
     const int32_t* sorted;
     const double2* sxy;
-    const int rc = build_hash(h, plon, plat, P, max_dist, &g, &start, &sorted, &sxy);
+    const unsigned* scan_error;
+    const int rc = build_hash(h, plon, plat, P, max_dist, &g, &start, &sorted, &sxy, &scan_error);
     if (rc != OISAT_OK) return rc;
     unsigned* count = nullptr;
-    unsigned* count_host = nullptr;
+    unsigned* count_host = (unsigned*)oisat_pinned(h, 64);
+    if (!count_host) return OISAT_ENOMEM;
     if (tie_list) {
         count = (unsigned*)oisat_ws(h, 1, 64);
-        count_host = (unsigned*)oisat_pinned(h, 64);
-        if (!count || !count_host) return OISAT_ENOMEM;
+        if (!count) return OISAT_ENOMEM;
         HIP_TRY(hipMemsetAsync(count, 0, 64, h->stream));
     }
     // latency-bound (dependent loads through the hash): one target per thread up to 16,384 blocks
     const int64_t qgrid = cdiv(Tn, 256) < 16384 ? cdiv(Tn, 256) : 16384;
     OISAT_LAUNCH(h, "nn_query", nn_query_kernel, dim3((unsigned)qgrid), dim3(256), 0, plon, plat, tlon, tlat, Tn, g, start,
                  sorted, sxy, max_dist, idx_out, dist_out, tie_list, count);
-    if (tie_list) {
-        HIP_TRY(hipMemcpyAsync(count_host, count, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
-        *n_ties = (int64_t)count_host[0];
-    }
-    return OISAT_OK;
+    // one small read-back per query (the callers download the indices next anyway): the tie count and the scan's error word
+    if (tie_list) HIP_TRY(hipMemcpyAsync(count_host, count, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(count_host + 1, scan_error, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (tie_list) *n_ties = (int64_t)count_host[0];
+    return scan_error_check(count_host + 1);
 }
 
 extern "C" int oisat_nn_query(oisat_ctx* h, const double* plon, const double* plat, int64_t P, const double* tlon,
@@ -916,7 +931,8 @@ extern "C" int oisat_rbf_interp(oisat_ctx* h, int dtype, const double* plon, con
     HashGrid g;
     const unsigned* start;
     const int32_t* sorted;
-    int rc = build_hash(h, plon, plat, P, cell, &g, &start, &sorted);
+    const unsigned* scan_error;
+    int rc = build_hash(h, plon, plat, P, cell, &g, &start, &sorted, nullptr, &scan_error);
     if (rc != OISAT_OK) return rc;
     int* flag = (int*)oisat_ws(h, 1, 64);
     int* flag_host = (int*)oisat_pinned(h, 64);
@@ -928,9 +944,10 @@ extern "C" int oisat_rbf_interp(oisat_ctx* h, int dtype, const double* plon, con
         rc = rbf_launch<double>(h, neighbors, plon, plat, tlon, tlat, Tn, nn_idx, g, start, sorted, values, P, nfields, out, flag);
     if (rc != OISAT_OK) return rc;
     HIP_TRY(hipMemcpyAsync(flag_host, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(flag_host + 1, scan_error, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (n_singular) *n_singular = flag_host[0];
-    return OISAT_OK;
+    return scan_error_check((const unsigned*)(flag_host + 1));
 }
 
 static int linear_impl(oisat_ctx* h, int dtype, const double* tlon, const double* tlat, int64_t Tn, const int32_t* nn_idx,

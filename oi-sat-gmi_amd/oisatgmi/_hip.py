@@ -7,6 +7,7 @@ infrastructure and is never imported from here.)
 """
 from __future__ import annotations
 
+import collections
 import ctypes as C
 import os
 import sys
@@ -101,7 +102,7 @@ SIGNATURES = {
     "oisat_batch_potrf": (C.c_int, [_c_ctx, C.c_int, C.POINTER(C.c_int)]),
     "oisat_batch_set_solve": (C.c_int, [_c_ctx, C.c_int, C.c_int] + [C.POINTER(_ptr)] * 11 + [C.POINTER(_i64)] + [C.POINTER(_ptr)] * 3),
     "oisat_set_task_graph": (C.c_int, [_c_ctx, C.c_int]),
-    "oisat_dag_task_order": (C.c_int, [C.c_int, _ptr, C.c_int, C.c_int, _ptr, _i64, C.POINTER(_i64), C.POINTER(C.c_int)]),
+    "oisat_dag_task_order": (C.c_int, [C.c_int, _ptr, C.c_int, _ptr, _i64, C.POINTER(_i64), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "oisat_batch_set_grid": (C.c_int, [_c_ctx, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(_ptr)]),
     "oisat_set_obs_blocks": (C.c_int, [_c_ctx, _ptr, _i64]),
     "oisat_batch_solve": (C.c_int, [_c_ctx, C.c_int, C.c_int, C.c_double, C.c_int]),
@@ -113,6 +114,7 @@ SIGNATURES = {
     "oisat_comm_gather": (C.c_int, [_c_ctx, _ptr, C.c_size_t, _ptr, C.c_int]),
     "oisat_comm_destroy": (C.c_int, [_c_ctx]),
     "oisat_solve_status": (C.c_int, [_c_ctx, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]),
+    "oisat_solve_status_ex": (C.c_int, [_c_ctx, C.POINTER(C.c_int32), C.c_int, C.c_int]),
     "oisat_dense_reserve": (C.c_int, [_c_ctx, _i64, _i64]),
 }
 
@@ -173,6 +175,22 @@ def load_library():
         return lib
 
 
+def load_test_hooks_library():
+    """The -DOISAT_TEST_HOOKS build of the library (csrc/Makefile: fault injection into the task-graph launch, read from
+    OISAT_DAG_FLAGS there and nowhere else).  For tests/test_gpu_dag.py: ``Context(device, lib=load_test_hooks_library())``;
+    the product never loads it."""
+    load_library()                                          # (torch's HIP runtime first, as above)
+    path = os.path.join(os.path.dirname(library_path()), "liboisat_hip_testhooks.so")
+    if not os.path.exists(path):
+        raise OisatUnavailable(f"{path} not found: `make -C oi-sat-gmi_amd/csrc` builds it next to the product library")
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
 def dtype_code(dt) -> int:
     dt = np.dtype(dt)
     if dt == np.float32:
@@ -194,6 +212,15 @@ def compute_dtype(*arrays) -> np.dtype:
         if np.asarray(a).dtype != np.float32:
             return np.dtype(np.float64)
     return np.dtype(np.float32)
+
+
+class SolveStatus(collections.namedtuple("SolveStatus", "notpd_col notpd_blocks trsv_timeouts unconverged unconverged_member dag_timeouts")):
+    """include/oisat.h ``OISAT_STATUS_*``; ``clean``: nothing to report."""
+    __slots__ = ()
+
+    @property
+    def clean(self) -> bool:
+        return not (self.notpd_col or self.notpd_blocks or self.trsv_timeouts or self.unconverged or self.dag_timeouts)
 
 
 class DeviceBuffer:
@@ -239,8 +266,8 @@ class DeviceBuffer:
 class Context:
     """One handle per process and device: ``oisat_init`` + the handle's stream."""
 
-    def __init__(self, device: int):
-        self.lib = load_library()
+    def __init__(self, device: int, lib=None):
+        self.lib = lib if lib is not None else load_library()
         h = _c_ctx()
         rc = self.lib.oisat_init(int(device), C.byref(h))
         if rc != 0:
@@ -358,19 +385,30 @@ class Context:
         self.check(self.lib.oisat_device_info(self.h, name, 128, C.byref(cu), C.byref(hbm)))
         return {"name": name.value.decode(), "cu_count": cu.value, "hbm_bytes": hbm.value}
 
-    def solve_status(self, clear=True):
-        """(first non-PD column, failing diagonal blocks, triangular-solve time-outs) since the last clear."""
-        a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
-        self.check(self.lib.oisat_solve_status(self.h, C.byref(a), C.byref(b), C.byref(c), 1 if clear else 0))
-        return a.value, b.value, c.value
+    def solve_status(self, clear=True) -> "SolveStatus":
+        """The six status words of ``oisat_solve_status_ex`` since the last clear."""
+        w = (C.c_int32 * len(SolveStatus._fields))()
+        self.check(self.lib.oisat_solve_status_ex(self.h, w, len(SolveStatus._fields), 1 if clear else 0))
+        return SolveStatus(*(int(x) for x in w))
 
     def check_solves(self, what="dense analysis"):
-        """Raise ``OisatError`` if any unchecked dense solve on this handle failed since the last check."""
-        col, nblk, nto = self.solve_status(clear=True)
-        if col or nblk or nto:
-            raise OisatError(f"{what}: " + "; ".join(
-                ([f"H B H^T + R not positive definite (first bad column {col}, {nblk} diagonal block(s))"] if (col or nblk) else [])
-                + ([f"{nto} triangular-solve workgroup(s) gave up waiting: z holds NaN fill"] if nto else [])))
+        """Raise ``OisatError`` if any unchecked dense solve on this handle failed since the last check: a non-positive
+        pivot, a time-out of the task graph or of a triangular sweep, or a refinement that used all its rounds and ended
+        above its tolerance."""
+        st = self.solve_status(clear=True)._asdict()
+        msgs = []
+        if st["notpd_col"] or st["notpd_blocks"]:
+            msgs.append(f"H B H^T + R not positive definite (first bad column {st['notpd_col']}, {st['notpd_blocks']} diagonal block(s))")
+        if st["dag_timeouts"]:
+            msgs.append(f"{st['dag_timeouts']} task-graph factorization(s) timed out: incomplete factor")
+        if st["trsv_timeouts"]:
+            msgs.append(f"{st['trsv_timeouts']} triangular-solve workgroup(s) gave up waiting: z holds NaN fill")
+        if st["unconverged"]:
+            who = f", first: batch member {st['unconverged_member']}" if st["unconverged_member"] >= 0 else ""
+            msgs.append(f"{st['unconverged']} gain solve(s) ended above the refinement tolerance after every allowed round{who} "
+                        "(raise `refine`, or the observation error / lower the correlation length: the fp32 factor is a poor preconditioner)")
+        if msgs:
+            raise OisatError(f"{what}: " + "; ".join(msgs))
 
     # ---- profiling
     def prof_enable(self, on=True):

@@ -115,7 +115,14 @@ def agree(error=None, device="cpu", dtype=None):
     agree on the widest slab dtype, which is returned (None if no rank has one)."""
     import torch
     dist = _dist()
-    code = -1 if dtype is None else _SLAB_DTYPES.index(str(dtype).replace("torch.", ""))
+    code = -1
+    if dtype is not None:
+        name = str(dtype).replace("torch.", "")
+        if name in _SLAB_DTYPES:
+            code = _SLAB_DTYPES.index(name)
+        elif error is None:                                  # an analysis that returned integers, say: this rank's failure -- it
+            error = ValueError(f"rank {dist.get_rank()}: an analysis returned dtype {name}; the gathered slab takes one of "
+                               f"{', '.join(_SLAB_DTYPES)}")          # still enters the all-reduce, so that every rank raises
     word = torch.tensor([0 if error is None else 1 + dist.get_rank(), code], dtype=torch.int32, device=device)
     dist.all_reduce(word, op=dist.ReduceOp.MAX)
     failed, code = int(word[0]), int(word[1])

@@ -2,7 +2,7 @@
 patch-wise increment.  The reference has no dense factorization (optimal_interpolation.py:27 is element-wise), so the checks
 are the factorization's own: L L^T against the matrix in float64, agreement with the recursive schedule, bitwise
 repeatability, the triangular solves through the factor, error reporting -- on single systems from one block row up and on
-mixed batches that exercise chains, chain servers, waves and the CU reservation."""
+mixed batches that exercise chains, waves and the CU reservation."""
 import ctypes as C
 import os
 
@@ -73,20 +73,13 @@ def test_task_graph_factor_against_the_matrix_and_the_recursion(ctx, m):
 def test_task_graph_is_bitwise_repeatable(ctx):
     """A tile's products are accumulated in column order whatever the moment its inputs arrive (the K-loop is cut into
     segments by availability, never reordered): two runs of the same system give the same bits, and so does a run whose
-    chain shares its CU (no reservation) and one without the consumers' acquires (producer-side L1 drops alone)."""
-    m = 2500
-    build, mp, keep = _system(ctx, m, 77)
-    S = ctx.alloc(mp * mp * 4)
-    a = _factor(ctx, build, S, m, mp, 1)
-    b = _factor(ctx, build, S, m, mp, 1)
-    assert np.array_equal(np.tril(a), np.tril(b))
-    for name, val in (("OISAT_DAG_RESERVE", "0"), ("OISAT_DAG_FLAGS", "1")):
-        os.environ[name] = val
-        try:
-            c = _factor(ctx, build, S, m, mp, 1)
-        finally:
-            del os.environ[name]
-        assert np.array_equal(np.tril(a), np.tril(c)), name
+    system of fewer than eight block rows, whose chain shares its CU (no reservation)."""
+    for m, seed in ((2500, 77), (900, 78)):
+        build, mp, keep = _system(ctx, m, seed)
+        S = ctx.alloc(mp * mp * 4)
+        a = _factor(ctx, build, S, m, mp, 1)
+        b = _factor(ctx, build, S, m, mp, 1)
+        assert np.array_equal(np.tril(a), np.tril(b))
 
 
 def test_task_graph_reports_a_non_positive_pivot_and_drains(ctx):
@@ -108,18 +101,18 @@ def test_task_graph_reports_a_non_positive_pivot_and_drains(ctx):
     A[300, 300] = -1.0
     S = ctx.upload(A)
     ctx.check(lib.oisat_potrf(ctx.h, S.ptr, m, m, None))
-    col, nblk, nto = ctx.solve_status(clear=True)
+    col, nblk, nto = ctx.solve_status(clear=True)[:3]
     assert col == 301 and nblk >= 1 and nto == 0
 
 
-@pytest.mark.parametrize("env", [{}, {"OISAT_DAG_WAVE": "2"}, {"OISAT_DAG_SERVE": "3", "OISAT_DAG_WAVE": "5"}, {"OISAT_DAG_RESERVE": "0"}])
-def test_task_graph_batch_of_mixed_sizes(ctx, env):
-    """oisat_batch_potrf as ONE task-graph launch over 11 systems of 1 .. 17 block rows: every member's factor agrees with
-    its own oisat_potrf (recursion) to fp32 rounding and reproduces its matrix; with small waves (systems enter the launch
-    two at a time), with chain servers (three small systems per chain workgroup) and without the CU reservation."""
+@pytest.mark.parametrize("sizes", [[2100, 1500, 1290, 1000, 777, 640, 300, 257, 129, 128, 100],
+                                   [2100, 640, 600, 520, 500, 480, 300, 300, 257, 257, 200, 129, 128, 100, 90, 64]])
+def test_task_graph_batch_of_mixed_sizes(ctx, sizes):
+    """oisat_batch_potrf as ONE task-graph launch over systems of 1 .. 17 block rows: every member's factor agrees with its own
+    oisat_potrf (recursion) to fp32 rounding and reproduces its matrix; a wave 0 of five systems (the first list) and a wave 0 of
+    one followed by two waves of eight and seven (the second)."""
     lib = ctx.lib
-    sizes = [2100, 1500, 1290, 1000, 777, 640, 300, 257, 129, 128, 100]
-    os.environ.update(env)
+    env = {}
     try:
         mats, refs = [], []
         for k, m in enumerate(sizes):
@@ -328,7 +321,7 @@ def test_task_graph_under_concurrent_uneven_load_is_bitwise_stable(ctx):
                 bad.append((tag, n, int((got != ref).sum())))
             n += 5
         counts[tag] = n
-        if any(c.solve_status(clear=True)):
+        if not c.solve_status(clear=True).clean:
             bad.append((tag, "status"))
         c.close()
 
@@ -358,27 +351,45 @@ def test_task_graph_under_concurrent_uneven_load_is_bitwise_stable(ctx):
 
 
 def test_task_graph_time_out_drains_the_launch_and_is_reported(ctx):
-    """Fault injection (OISAT_DAG_FLAGS = 128 | 256: the chains stop announcing their diagonal blocks at block 3, polls give up
-    after 4 096 rounds): the waiting tile tasks time out, raise the launch's error word, every other workgroup sees it and
-    leaves -- the launch ends within milliseconds instead of hanging --, the time-out is reported through the status words
-    (oisat_solve_status), and the NEXT factorization on the same plan finds the progress words clean and is correct."""
-    lib = ctx.lib
+    """Fault injection -- only the -DOISAT_TEST_HOOKS build of the library has it (liboisat_hip_testhooks.so; OISAT_DAG_FLAGS =
+    128 | 256 there: the chains stop announcing their diagonal blocks at block 3, polls give up after 4 096 rounds): the waiting
+    tile tasks time out, raise the launch's error word, every other workgroup sees it and leaves -- the launch ends within
+    milliseconds instead of hanging --, the time-out is reported as a TASK-GRAPH time-out (its own status word; the checked call
+    returns an error that names the factorization), and the NEXT factorization on the same plan finds the progress words clean
+    and is correct.  The product library ignores the variable."""
+    hooks = _hip.Context(ctx.device, lib=_hip.load_test_hooks_library()).own_stream()
+    lib = hooks.lib
     m = 1500
-    build, mp, keep = _system(ctx, m, 4242)
-    S = ctx.alloc(mp * mp * 4)
-    good = _factor(ctx, build, S, m, mp, 1)
-    ctx.solve_status(clear=True)
+    build, mp, keep = _system(hooks, m, 4242)
+    S = hooks.alloc(mp * mp * 4)
+    good = _factor(hooks, build, S, m, mp, 1)
+    hooks.solve_status(clear=True)
     os.environ["OISAT_DAG_FLAGS"] = str(128 | 256)
     try:
         build(S)
-        ctx.check(lib.oisat_set_task_graph(ctx.h, 1))
-        ctx.check(lib.oisat_potrf(ctx.h, S.ptr, m, mp, None))
-        ctx.sync()
+        hooks.check(lib.oisat_set_task_graph(hooks.h, 1))
+        hooks.check(lib.oisat_potrf(hooks.h, S.ptr, m, mp, None))
+        hooks.sync()
+        st = hooks.solve_status(clear=True)
+        assert st.dag_timeouts >= 1 and st.trsv_timeouts == 0 and st.notpd_col == 0 and not st.clean
+        build(S)
+        info = C.c_int(-1)
+        rc = lib.oisat_potrf(hooks.h, S.ptr, m, mp, C.byref(info))          # checked: the call itself says what happened
+        assert rc != 0 and "task-graph factorization timed out" in lib.oisat_last_error().decode()
+        assert hooks.solve_status(clear=True).clean                          # reported once
+        with pytest.raises(_hip.OisatError, match="task-graph factorization"):
+            build(S)
+            hooks.check(lib.oisat_potrf(hooks.h, S.ptr, m, mp, None))
+            hooks.check_solves()
+        # the product library does not know the variable
+        build2, mp2, keep2 = _system(ctx, m, 4242)
+        S2 = ctx.alloc(mp2 * mp2 * 4)
+        assert np.array_equal(np.tril(_factor(ctx, build2, S2, m, mp2, 1)), np.tril(good))
+        assert ctx.solve_status(clear=True).clean
     finally:
         del os.environ["OISAT_DAG_FLAGS"]
-    col, nblk, nto = ctx.solve_status(clear=True)
-    assert nto >= 1 and col == 0
-    again = _factor(ctx, build, S, m, mp, 1)
+    again = _factor(hooks, build, S, m, mp, 1)
     assert np.array_equal(np.tril(again), np.tril(good))
-    assert ctx.solve_status(clear=True) == (0, 0, 0)
-    ctx.check(lib.oisat_set_task_graph(ctx.h, -1))
+    assert hooks.solve_status(clear=True).clean
+    hooks.close()
+    ctx.check(ctx.lib.oisat_set_task_graph(ctx.h, -1))

@@ -315,7 +315,7 @@ def test_unchecked_runs_cannot_fail_silently(ctx):
     plan.run(600.0, refine=1)                             # unchecked: returns at once
     with pytest.raises(_hip.OisatError, match="not positive definite"):
         plan.download()
-    assert plan.ctx.solve_status() == (0, 0, 0)           # the failure was reported once and cleared
+    assert plan.ctx.solve_status().clean           # the failure was reported once and cleared
     with pytest.raises(_hip.OisatError):                  # the checked form still reports its own factorization
         plan.run(600.0, refine=1, check_pd=True)
     plan.ctx.solve_status(clear=True)
@@ -447,7 +447,7 @@ def test_batched_factorization_is_bit_identical(ctx):
     with pytest.raises(_hip.OisatError, match="matrix 1 not positive definite at column 201"):
         ctx.check(lib.oisat_batch_potrf(ctx.h, bid.value, info2))
     assert list(info2) == [201, 1]
-    assert ctx.solve_status() == (0, 0, 0)                    # reported through the return code, not twice
+    assert ctx.solve_status().clean                    # reported through the return code, not twice
     Lg = np.tril(ctx.download(Gb.ptr, (384, 384), np.float32)).astype(np.float64)
     assert np.abs(Lg @ Lg.T - good).max() <= 1e-5             # the good member is still factored
     ctx.check(lib.oisat_batch_destroy(ctx.h, bid.value))
@@ -708,7 +708,7 @@ def test_diagonal_block_kernel_edge_sizes_and_every_pivot_position(ctx, m):
                 ctx.check(lib.oisat_potrf(ctx.h, Bb.ptr, m, mp, C.byref(info)))
             assert info.value == col + 1, (col, info.value)
             Bb.free()
-        assert ctx.solve_status() == (0, 0, 0)              # checked failures leave nothing sticky behind
+        assert ctx.solve_status().clean              # checked failures leave nothing sticky behind
 
 
 @pytest.mark.gpu

@@ -180,7 +180,7 @@ def test_tile_partition_polar_caps_and_halo():
 # ------------------------------------------------------------------------------------------------
 # task-graph factorization: the ticket order (csrc/dense_dag.inc), checked on the host
 # ------------------------------------------------------------------------------------------------
-def _dag_order(block_rows, wave=0, serve=-1):
+def _dag_order(block_rows, wave=0):
     import ctypes as C
     from oisatgmi import _hip
     if not os.path.exists(_hip.library_path()):
@@ -188,34 +188,32 @@ def _dag_order(block_rows, wave=0, serve=-1):
         g.build()
     lib = C.CDLL(_hip.library_path())
     lib.oisat_dag_task_order.restype = C.c_int
-    lib.oisat_dag_task_order.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int)]
+    lib.oisat_dag_task_order.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int),
+                                         C.POINTER(C.c_int)]
     nb = np.asarray(block_rows, dtype=np.int32)
-    n, res = C.c_int64(0), C.c_int(0)
-    assert lib.oisat_dag_task_order(len(nb), nb.ctypes.data, wave, serve, None, 0, C.byref(n), C.byref(res)) == 0
+    n, res, mwc = C.c_int64(0), C.c_int(0), C.c_int(0)
+    assert lib.oisat_dag_task_order(len(nb), nb.ctypes.data, wave, None, 0, C.byref(n), C.byref(res), C.byref(mwc)) == 0
     out = np.zeros((n.value, 4), dtype=np.int32)
-    assert lib.oisat_dag_task_order(len(nb), nb.ctypes.data, wave, serve, out.ctypes.data, n.value, C.byref(n), C.byref(res)) == 0
-    return out, res.value
+    assert lib.oisat_dag_task_order(len(nb), nb.ctypes.data, wave, out.ctypes.data, n.value, C.byref(n), C.byref(res), C.byref(mwc)) == 0
+    return out, res.value, mwc.value
 
 
-@pytest.mark.parametrize("block_rows,wave,serve", [([79], 0, -1), (sorted([137, 137] + [48, 47, 45, 44, 40, 33, 31] * 6, reverse=True), 8, 0),
-                                                   ([17, 12, 11, 8, 7, 5, 3, 3, 2, 1, 1], 2, 0), ([20, 9, 9, 8, 8, 7, 3, 2, 1], 5, 3)])
-def test_task_graph_ticket_order_is_topological_and_complete(block_rows, wave, serve):
+MONTH = sorted([137, 137] + [48, 47, 45, 44, 40, 33, 31] * 6 + [46] * 6, reverse=True)       # block rows of a localised 720x1440 month
+
+
+@pytest.mark.parametrize("block_rows,wave", [([79], 0), (MONTH, 8), ([17, 12, 11, 8, 7, 5, 3, 3, 2, 1, 1], 2), ([20, 9, 9, 8, 8, 7, 3, 2, 1], 5)])
+def test_task_graph_ticket_order_is_topological_and_complete(block_rows, wave):
     """Every tile of every system is owned by exactly one task, and every input of a task carries a LOWER ticket or is a step of
-    its system's chain, whose own ticket is lower -- the property that lets the launch drain with any number of resident
-    workgroups (csrc/dense_dag.inc).  Inputs of a task on tile (i, j) of system s: the final blocks L(i, k), L(j, k), k < j
-    (k < j - 1 for PRE), each produced by the tile task T(., k) of that row -- or by the chain for the sub-diagonal tile -- and
-    the diagonal block j (chain)."""
-    tasks, reserve = _dag_order(block_rows, wave, serve)
+    its system's chain, whose own ticket is lower (csrc/dense_dag.inc).  Inputs of a task on tile (i, j) of system s: the final
+    blocks L(i, k), L(j, k), k < j (k < j - 1 for PRE), each produced by the tile task T(., k) of that row -- or by the chain for
+    the sub-diagonal tile -- and the diagonal block j (chain)."""
+    tasks, reserve, _ = _dag_order(block_rows, wave)
     ticket = {}
     chain_ticket = {}
     for t, (kind, s, i, j) in enumerate(tasks.tolist()):
         if kind == 0:
             assert s not in chain_ticket
             chain_ticket[s] = t
-        elif kind == 4:
-            for q in range(s, s + i):
-                assert q not in chain_ticket
-                chain_ticket[q] = t
         else:
             assert (s, i, j) not in ticket
             ticket[(s, i, j)] = (t, kind)
@@ -236,6 +234,18 @@ def test_task_graph_ticket_order_is_topological_and_complete(block_rows, wave, s
                     # r == k + 1: the chain's panel tile; r == k cannot happen (k < j <= i)
     # the chains that get a CU to themselves hold the first tickets
     assert all(tasks[t][0] == 0 for t in range(reserve))
+
+
+def test_task_graph_chains_must_leave_room_for_the_tasks_they_wait_for():
+    """a chain waits for sub(j) / pre(j+1), which come from HIGHER tickets -- if every resident workgroup held a chain
+    nobody would draw them.  The library counts the chains that can be resident at one time (the largest wave's plus those of
+    one more wave behind wave 0: a wave's chains still walk their last columns when the next wave's are drawn) and only
+    launches a task graph on four times as many workgroups; this is that count."""
+    assert _dag_order([79])[2] == 1
+    assert _dag_order(MONTH)[2] == 8 + 8                               # two polar caps, then eight tiles at a time
+    assert _dag_order([40] * 100)[2] == 64 + 8                         # wave 0 holds at most 64 chains
+    assert _dag_order([40] * 30, wave=3)[2] == 30                      # all of them within a factor two: one wave
+    assert _dag_order([40, 40] + [10] * 30, wave=20)[2] == 20 + 20
 
 
 def _run_bench(*argv, env_extra=None):

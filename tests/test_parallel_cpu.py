@@ -208,6 +208,15 @@ def _failing_worker(rank, world, port, q):
             out["gather"] = "remote"
         except RuntimeError:
             out["gather"] = "own"
+        # (3b) ADVICE r3: one rank's analysis returns a dtype the slab cannot take (integers): that rank used to raise BEFORE
+        # the all-reduce and leave the other one waiting in it; now it is that rank's failure, carried through the all-reduce
+        try:
+            parallel.analyse_units(range(2), lambda u: torch.zeros(2, dtype=torch.int32 if rank == 1 else torch.float32), result_shape=(2,))
+            out["dtype"] = "no error"
+        except parallel.RemoteRankError:
+            out["dtype"] = "remote"
+        except ValueError:
+            out["dtype"] = "own"
         # (4) and the group is still usable afterwards: a clean run, rank 1's shard EMPTY and no dtype given --
         # the slab dtype is agreed across ranks (float64 from rank 0's results), not defaulted per rank
         res = parallel.analyse_units(["only"], lambda u: torch.full((2,), 7.0, dtype=torch.float64), result_shape=(2,))
@@ -235,6 +244,7 @@ def test_a_failing_rank_stops_every_rank_instead_of_hanging_the_gather():
     assert got[owner3]["units"] == "own" and got[1 - owner3]["units"].startswith("remote")
     assert got[0]["finish"] == "own" and got[1]["finish"] == "remote"
     assert got[1]["gather"] == "own" and got[0]["gather"] == "remote"
+    assert got[1]["dtype"] == "own" and got[0]["dtype"] == "remote"
     assert got[0]["after"] and got[1]["after"]
     assert max(g["seconds"] for g in got.values()) < 20
 

@@ -51,7 +51,7 @@ def worker(tag, m, seed, own):
             mismatch.append((tag, n, len(bad), tuple(bad[0])))
         n += 5
     counts[tag] = n
-    col, nblk, nto = c.solve_status(clear=True)
+    col, nblk, nto = c.solve_status(clear=True)[:3]
     if col or nblk or nto:
         mismatch.append((tag, "status", col, nblk, nto))
 
@@ -97,7 +97,7 @@ def batch_worker(tag, sizes, seed, env):
                 mismatch.append((tag, it, k, int((g != r).sum())))
         it += 3
     counts[tag] = it
-    col, nblk, nto = c.solve_status(clear=True)
+    col, nblk, nto = c.solve_status(clear=True)[:3]
     if col or nblk or nto:
         mismatch.append((tag, "status", col, nblk, nto))
 
