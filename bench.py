@@ -67,8 +67,8 @@ def parse():
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--tier-a-only", action="store_true", help="run only the reference-parity (Tier-A) kernel legs (profiling aid)")
     ap.add_argument("--only", default="", help="profiling aid: comma list of legs to run INSTEAD of the whole bench -- tiled, "
-                    "secondary (config 2 alone), config4, pcie, regrid; prints {leg: result}")
-    ap.add_argument("--no-config4", action="store_true", help="skip the fixed-workload strong-scaling leg (12 months x tiles)")
+                    "secondary (config 2 alone), config4, config5, pcie, regrid; prints {leg: result}")
+    ap.add_argument("--no-config4", action="store_true", help="skip the fixed-workload strong-scaling legs (12 months x tiles; 3 species x tiles)")
     ap.add_argument("--c4-months", type=int, default=12)
     ap.add_argument("--c4-passes", type=int, default=2)
     ap.add_argument("--c4-shards", default="", help="e.g. 1,2,4,8: emulate the config-4 strong-scaling curve on ONE GPU by timing "
@@ -153,6 +153,15 @@ def roofline_leg(ctx, plan, L, refine, psteps):
         "algorithmic_flops_per_step": chol_flops, "kernel_ms_per_step": gemm_ms, "launches_per_step": gemm_launches,
         "avg_launch_ms": gemm_ms / gemm_launches if gemm_launches else None,
     }
+    if dag and m <= 90000:                                # config 2: its own PMC passes (tools/pmc_traffic.sh ... bench.py --only secondary)
+        tj, src = _newest_profile("r*_c2_hbm_traffic_pmc.json")
+        if tj and "potrf_dag_kernel" in tj.get("kernels", {}):
+            roof["traffic"] = tj["kernels"]["potrf_dag_kernel"]["bytes_per_dispatch"]
+            roof["traffic_source"] = f"{src} at commit {tj.get('commit')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2; bytes per launch)"
+        bj, bsrc = _newest_profile("r*_c2_mfma_busy_pmc.json")
+        if bj and bj.get("mfma_busy_fraction") is not None:
+            roof["mfma_busy_fraction"] = bj["mfma_busy_fraction"]
+            roof["mfma_busy_source"] = f"{bsrc} at commit {bj.get('commit')}"
     per_kernel = {k: round(v["total_ms"] / psteps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
     return roof, per_kernel
 
@@ -320,22 +329,72 @@ def pcie_leg(sync):
     return out
 
 
+def _newest_profile(pattern):
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    return (json.load(open(files[-1])), "profiles/" + os.path.basename(files[-1])) if files else (None, None)
+
+
+def _dag_roofline(prof_by_handle, flops_per_run, runs, tag, what):
+    """MFMA roofline of the task-graph launch(es) of a leg: achieved = algorithmic flops (sum over the systems of m^3/3) /
+    the launch's duration, HIP events on the launch stream; traffic / MFMA-busy from the newest PMC passes of this same leg
+    under profiles/ (tools/pmc_traffic.sh, tools/pmc_busy.sh: `bench.py --only <leg>`, program directly after `--`)."""
+    ms = sum(pr["potrf_dag"]["total_ms"] for pr in prof_by_handle if "potrf_dag" in pr) / runs
+    launches = sum(pr["potrf_dag"]["launches"] for pr in prof_by_handle if "potrf_dag" in pr) / runs
+    if ms <= 0:
+        return None
+    achieved = flops_per_run / (ms * 1e-3) / 1e12
+    roof = {"bound": "mfma", "kernel": what, "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / MFMA_F32_PEAK_TFLOPS, "algorithmic_flops_per_step": flops_per_run, "kernel_ms_per_step": ms,
+            "launches_per_step": launches, "traffic": None, "mfma_busy_fraction": None}
+    tj, src = _newest_profile(f"r*_{tag}_hbm_traffic_pmc.json")
+    if tj and "potrf_dag_kernel" in tj.get("kernels", {}):
+        roof["traffic"] = tj["kernels"]["potrf_dag_kernel"]["bytes_per_dispatch"]
+        roof["traffic_source"] = f"{src} at commit {tj.get('commit')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2; bytes per launch)"
+        roof["flop_per_byte_at_the_fabric"] = flops_per_run / launches / roof["traffic"] if launches else None
+    bj, bsrc = _newest_profile(f"r*_{tag}_mfma_busy_pmc.json")
+    if bj and bj.get("mfma_busy_fraction") is not None:
+        roof["mfma_busy_fraction"] = bj["mfma_busy_fraction"]
+        roof["mfma_busy_source"] = f"{bsrc} at commit {bj.get('commit')} (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 128), last launch)"
+    return roof
+
+
 def tiled_leg(ctx, workload, sync):
-    """BASELINE configs[2] as worded: localised block-B -- 30 deg x 30 deg tiles, halo 3 L."""
+    """BASELINE configs[2] as worded: localised block-B -- 30 deg x 30 deg tiles, halo 3 L -- with its own roofline object:
+    the month's ONE task-graph launch (factorization of all 50 systems, and -- round 4 -- their gain solves and increments)."""
     from oisatgmi import dense
     ny, nx, nobs, L, swaths, refine = WORKLOADS[workload]
     p, cell, lat2, lon2 = build_case(workload, 4000)
     ta = dense.TiledAnalysis(lat2, lon2, tile_deg=30.0, halo_km=3.0 * L, dtype=np.float32, ctx=ctx)
     ta.load(p.Xa, p.Sa, p.obs_lat, p.obs_lon, p.obs_y, p.obs_var)
     ta.run(L, refine=refine, check_pd=True)
-    el = time_steps(lambda: ta.run(L, refine=refine), 3, 1, sync)
+    steps = 5
+    el = time_steps(lambda: ta.run(L, refine=refine), steps, 1, sync)
     sizes = [int(t["obs"].size) for t in ta.tiles]
-    return {"workload": f"{workload}, localised block-B: {len(ta.tiles)} tiles (30x30 deg; each polar band is one cap tile, its "
-                        f"observation set being the same at every longitude), halo {3.0 * L:.0f} km",
-            "solve_tflop_executed": ta.flops / 1e12,
-            "value": ny * nx * 3 / el, "unit": "grid-cells/s", "ms_per_step": 1e3 * el / 3,
-            "obs_per_tile_min_median_max": [min(sizes), int(np.median(sizes)), max(sizes)],
-            "solve_tflops_end_to_end": ta.flops / (el / 3) / 1e12}
+    chol_flops = sum(float(m) ** 3 / 3.0 for m in sizes)
+    handles = list(ta.factor.ctxs) if ta.factor is not None else []
+    for hc in handles:
+        hc.prof_reset()
+        hc.prof_enable(True)
+    for _ in range(3):
+        ta.run(L, refine=refine)
+    profs = [hc.prof_collect() for hc in handles]
+    for hc in handles:
+        hc.prof_enable(False)
+    per_kernel = {}
+    for pr in profs:
+        for k, v in pr.items():
+            per_kernel[k] = per_kernel.get(k, 0.0) + v["total_ms"] / 3
+    out = {"workload": f"{workload}, localised block-B: {len(ta.tiles)} tiles (30x30 deg; each polar band is one cap tile, its "
+                       f"observation set being the same at every longitude), halo {3.0 * L:.0f} km",
+           "solve_tflop_executed": ta.flops / 1e12,
+           "value": ny * nx * steps / el, "unit": "grid-cells/s", "ms_per_step": 1e3 * el / steps,
+           "obs_per_tile_min_median_max": [min(sizes), int(np.median(sizes)), max(sizes)],
+           "solve_tflops_end_to_end": ta.flops / (el / steps) / 1e12,
+           "roofline": _dag_roofline(profs, chol_flops, 3, "tiled", "potrf_dag_kernel over the month's 50 systems (polar caps + 30 deg tiles) as one "
+                                     "persistent launch"),
+           "group_stream_kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1])}}
+    ta.close()
+    return out
 
 
 def regrid_leg(ctx, sync):
@@ -463,34 +522,44 @@ def cpu_baseline(workload):
     out["regrid_type4_s_for_3_fields"] = time.perf_counter() - t1
     return out
 
-def _c4_workload(args, lat2, lon2):
-    """The fixed config-4 workload: (month x tile) units with their obs^3 weights and cell counts (seeded: every rank
-    derives the same months, nothing to broadcast)."""
-    from oisatgmi import synthetic as syn, dense
+def _month_cases(args):
+    """The fixed config-4 workload: `c4_months` seeded synthetic months (every rank derives the same ones, nothing to broadcast)."""
+    from oisatgmi import synthetic as syn
     ny, nx, nobs, L, swaths, refine = WORKLOADS[DEFAULT]
-    halo = 3.0 * L
-    cases, units, weights, cells = {}, [], [], []
-    for mth in range(args.c4_months):
-        p = syn.point_obs_case(ny, nx, nobs, 4000 + mth, swaths=swaths)
-        cases[mth] = p
+    return {mth: syn.point_obs_case(ny, nx, nobs, 4000 + mth, swaths=swaths) for mth in range(args.c4_months)}
+
+
+def _species_cases():
+    """The fixed config-5 workload: one 720x1440 month of each control_*.yml species (run/control_omino2.yml:23,
+    control_omihcho.yml, control_omio3.yml: value ranges, ctm_error, observation-error model)."""
+    from oisatgmi import synthetic as syn
+    ny, nx, nobs, L, swaths, refine = WORKLOADS[DEFAULT]
+    return {sp: syn.point_obs_case(ny, nx, nobs, 4000, swaths=swaths, species=sp) for sp in ("NO2", "HCHO", "O3")}
+
+
+def _c4_workload(cases, lat2, lon2):
+    """(analysis x tile) units of a dict of cases with their obs^3 weights and cell counts."""
+    from oisatgmi import dense
+    halo = 3.0 * WORKLOADS[DEFAULT][3]
+    units, weights, cells = [], [], []
+    for key, p in cases.items():
         for ti, t in enumerate(dense.tile_partition(lat2, lon2, p.obs_lat, p.obs_lon, 30.0, halo)):
             if t["obs"].size:
-                units.append((mth, ti))
+                units.append((key, ti))
                 weights.append(float(t["obs"].size) ** 3)
                 cells.append((t["rows"][1] - t["rows"][0]) * (t["cols"][1] - t["cols"][0]))
-    return cases, units, weights, cells
+    return units, weights, cells
 
 
-def _c4_shard(ctx, args, cases, units, part, lat2, lon2, cap):
-    """One rank's shard of the config-4 units as a MonthTileBatch on the lanes of one pool."""
+def _c4_shard(ctx, cases, units, part, lat2, lon2, cap):
+    """One rank's shard of the (analysis x tile) units as a MonthTileBatch on the lanes of one pool."""
     from oisatgmi import dense
     halo = 3.0 * WORKLOADS[DEFAULT][3]
     batch = dense.MonthTileBatch(lat2, lon2, 30.0, halo, np.float32, ctx=ctx, streams=12)
-    for mth in range(args.c4_months):
-        only = [units[i][1] for i in part if units[i][0] == mth]
+    for key, p in cases.items():
+        only = [units[i][1] for i in part if units[i][0] == key]
         if only:
-            p = cases[mth]
-            batch.add_month(mth, p.Xa, p.Sa, p.obs_lat, p.obs_lon, p.obs_y, p.obs_var, only=only)
+            batch.add_month(key, p.Xa, p.Sa, p.obs_lat, p.obs_lon, p.obs_y, p.obs_var, only=only)
     batch.build(min_slab_elems=cap)
     assert sorted((k, ti) for k, ti, _ in batch.units) == sorted(units[i] for i in part)
     return batch
@@ -506,7 +575,8 @@ def config4_shards_leg(ctx, args, lat2, lon2, sync, worlds):
     levels with few members, host enqueue) that do not shrink with the shard."""
     from oisatgmi import parallel
     _, _, _, L, _, refine = WORKLOADS[DEFAULT]
-    cases, units, weights, cells = _c4_workload(args, lat2, lon2)
+    cases = _month_cases(args)
+    units, weights, cells = _c4_workload(cases, lat2, lon2)
     out = {"workload": f"{args.c4_months} months x (720x1440, 1e5 swath obs) as {len(units)} (month x tile) units",
            "note": "single-GPU emulation: the W shards of a W-rank job timed one after the other on one MI355X; no gather"}
     base = None
@@ -515,7 +585,7 @@ def config4_shards_leg(ctx, args, lat2, lon2, sync, worlds):
         secs = []
         for r in range(W):
             cap = sum(2 * cells[i] for i in parts[r])
-            batch = _c4_shard(ctx, args, cases, units, parts[r], lat2, lon2, cap)
+            batch = _c4_shard(ctx, cases, units, parts[r], lat2, lon2, cap)
             batch.run(L, refine=refine, check_pd=True)
             batch.run(L, refine=refine, wait=False)
             batch.check()
@@ -537,24 +607,30 @@ def config4_shards_leg(ctx, args, lat2, lon2, sync, worlds):
     return out
 
 
-def config4_leg(ctx, args, world, rank, local, lat2, lon2, sync, barrier):
+def config4_leg(ctx, args, world, rank, local, lat2, lon2, sync, barrier, cases=None, label=None):
     """BASELINE configs[3], STRONG scaling: a FIXED workload -- `c4_months` synthetic 720x1440 months of 10^5 swath
     observations, each cut into 30 deg x 30 deg tiles with a 3 L halo (localised block-B) -- split into (month x tile)
     units, sharded over the ranks by obs^3-weighted LPT (parallel.partition_units), every rank running its whole shard
     on the lanes of one pool with no collective and no host synchronisation inside, and ONE gather of all `xa | inc`
     tiles to rank 0 at the end.  The same leg runs at every --gpus N (N = 1 included), so seconds(1) / seconds(N) is the
     strong-scaling curve (reference: one scheduler job per month, run/job_submitter_sbatch.py:45-68; with months as the
-    only unit 8 GPUs cap at 12/2 = 6.0x, hence the finer unit)."""
+    only unit 8 GPUs cap at 12/2 = 6.0x, hence the finer unit).
+    `cases` / `label`: another fixed dict of analyses through the same machinery -- BASELINE configs[4], the three species'
+    months as 3 x 50 (species x tile) units (`config5_strong`)."""
     import torch
     import torch.distributed as dist
     from oisatgmi import dense, parallel
     ny, nx, nobs, L, swaths, refine = WORKLOADS[DEFAULT]
     halo = 3.0 * L
-    cases, units, weights, cells = _c4_workload(args, lat2, lon2)
+    if cases is None:
+        cases = _month_cases(args)
+        label = f"{args.c4_months} months x (720x1440, 1e5 swath obs)"
+    nanalyses = len(cases)
+    units, weights, cells = _c4_workload(cases, lat2, lon2)
     parts = parallel.partition_units(len(units), world, weights)
     loads = [sum(weights[i] for i in part) for part in parts]
     cap = max(sum(2 * cells[i] for i in part) for part in parts)      # slab elements every rank sends
-    batch = _c4_shard(ctx, args, cases, units, parts[rank], lat2, lon2, cap)
+    batch = _c4_shard(ctx, cases, units, parts[rank], lat2, lon2, cap)
     del cases
     send = torch.as_tensor(parallel.DeviceView(batch.slab.ptr, cap, "<f4"), device=torch.device("cuda", local))
 
@@ -598,10 +674,9 @@ def config4_leg(ctx, args, world, rank, local, lat2, lon2, sync, barrier):
             ok = ok and bool(np.isfinite(host[:used]).all()) and bool(np.any(host[:used] != 0))
         sec = el / args.c4_passes
         flops = sum(dense.DenseAnalysis.flops(round(w ** (1.0 / 3.0))) for w in weights)
-        out = {"workload": f"{args.c4_months} months x (720x1440, 1e5 swath obs), localised block-B: 30 deg tiles (polar bands as single cap "
-                           f"tiles), halo {halo:.0f} km",
+        out = {"workload": f"{label}, localised block-B: 30 deg tiles (polar bands as single cap tiles), halo {halo:.0f} km",
                "scaling": "strong", "n_gpus": world, "units": len(units), "seconds": sec,
-               "value": args.c4_months * ny * nx / sec, "unit": "grid-cells/s",
+               "value": nanalyses * ny * nx / sec, "unit": "grid-cells/s",
                "solve_tflops_end_to_end": flops / sec / 1e12,
                "max_rank_load_over_mean": max(loads) / (sum(loads) / world),
                "speedup_bound_from_load_balance": sum(loads) / max(loads),
@@ -610,6 +685,14 @@ def config4_leg(ctx, args, world, rank, local, lat2, lon2, sync, barrier):
                "gather": "one dist.gather of %.1f MB per rank to rank 0 per pass" % (4e-6 * cap)}
     batch.close()
     return out
+
+
+def config5_leg(ctx, args, world, rank, local, lat2, lon2, sync, barrier):
+    """BASELINE configs[4] as a SHARDED workload: one 720x1440 month of each of NO2, HCHO and O3 (the three control_*.yml
+    parameter sets) = 3 x 50 (species x tile) units through the same partition / MonthTileBatch / one-gather machinery as
+    config 4, at every N (N = 1 included): seconds(1) / seconds(N) is its strong-scaling curve."""
+    return config4_leg(ctx, args, world, rank, local, lat2, lon2, sync, barrier, cases=_species_cases(),
+                       label="3 species (NO2, HCHO, O3: run/control_omino2.yml, control_omihcho.yml, control_omio3.yml shapes) x (720x1440, 1e5 swath obs)")
 
 
 def launch_command(ngpus, argv, port):
@@ -747,6 +830,9 @@ def main():
             elif leg == "config4":
                 lat2, lon2 = syn.global_grid(ny, nx)
                 res[leg] = config4_leg(ctx, args, 1, 0, local, lat2, lon2, sync, None)
+            elif leg == "config5":
+                lat2, lon2 = syn.global_grid(ny, nx)
+                res[leg] = config5_leg(ctx, args, 1, 0, local, lat2, lon2, sync, None)
             else:
                 raise SystemExit(f"--only: unknown leg {leg!r}")
         print(json.dumps(res))
@@ -892,8 +978,10 @@ def main():
         if world > 1:
             del plan                                       # its 40 GB factor goes back before the tile lanes allocate theirs
         c4 = config4_leg(ctx, args, world, rank, local, lat2, lon2, sync, barrier)
+        c5 = config5_leg(ctx, args, world, rank, local, lat2, lon2, sync, barrier)
         if rank == 0:
             out["config4_strong"] = c4
+            out["config5_strong"] = c5
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # last: its BLAS threads keep spinning for a while
         out["cpu_baseline"] = cpu_baseline(args.workload)
     if rank == 0:

@@ -314,3 +314,55 @@ def test_cached_single_system_plans_follow_their_buffers(ctx):
         factor(big, 300 + 128 * (k % 5), 1024 + 128 * (k % 3), 10 + k)
     assert c2.solve_status(clear=True).clean
     c2.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE configs[4] as a sharded workload -- (species x tile) units
+# ------------------------------------------------------------------------------------------------
+def test_config5_species_tile_units_at_full_size_on_one_gpu(ctx):
+    """Three 720x1440 / 1e5-observation months -- the NO2, HCHO and O3 parameter sets of run/control_omino2.yml:23,
+    control_omihcho.yml, control_omio3.yml -- cut into 3 x 50 (species x tile) units, ALL of them in one MonthTileBatch (what
+    `bench.py` leg config5_strong runs at N = 1), against each species' own TiledAnalysis: every tile of the slab equals the
+    per-species result to refinement accuracy (the batch's waves differ, so the fp32 factors differ in their last bits), each
+    species' relative to its own field scale (O3 is 200-500 DU next to NO2's 0.2-10)."""
+    from oisatgmi import parallel
+    L = 300.0
+    lat, lon = syn.global_grid(720, 1440)
+    cases = {sp: syn.point_obs_case(720, 1440, 100000, 4000, swaths=True, species=sp) for sp in ("NO2", "HCHO", "O3")}
+    units, weights = [], []
+    for sp, p in cases.items():
+        for ti, t in enumerate(dense.tile_partition(lat, lon, p.obs_lat, p.obs_lon, 30.0, 3 * L)):
+            if t["obs"].size:
+                units.append((sp, ti))
+                weights.append(float(t["obs"].size) ** 3)
+    assert len(units) == 150
+    for world, want in ((2, 1.98), (4, 3.9), (8, 7.0)):               # the partition itself balances (obs^3 weights)
+        parts = parallel.partition_units(len(units), world, weights)
+        loads = [sum(weights[i] for i in part) for part in parts]
+        assert sum(loads) / max(loads) >= want, (world, sum(loads) / max(loads))
+    batch = dense.MonthTileBatch(lat, lon, 30.0, 3 * L, np.float32, streams=12)
+    for sp, p in cases.items():
+        batch.add_month(sp, p.Xa, p.Sa, p.obs_lat, p.obs_lon, p.obs_y, p.obs_var)
+    batch.build()
+    assert sorted((k, ti) for k, ti, _ in batch.units) == sorted(units)
+    batch.run(L, refine=2, check_pd=True)
+    slab = batch.download_slab()
+    assert np.isfinite(slab).all()
+    for sp, p in cases.items():
+        ta = dense.TiledAnalysis(lat, lon, tile_deg=30.0, halo_km=3 * L, dtype=np.float32)
+        ta.load(p.Xa, p.Sa, p.obs_lat, p.obs_lon, p.obs_y, p.obs_var)
+        ta.run(L, refine=2)
+        xa, inc = ta.download()
+        ta.close()
+        tol = 5e-6 * np.abs(p.Xa).max()
+        worst = 0.0
+        for u, (key, ti, _) in enumerate(batch.units):
+            if key != sp:
+                continue
+            (y0, y1), (x0, x1) = ta.tiles[ti]["rows"], ta.tiles[ti]["cols"]
+            shape = batch.unit_shape(u)
+            got = slab[batch.offsets[u]: batch.offsets[u] + int(np.prod(shape))].reshape(shape)
+            worst = max(worst, np.abs(got[0] - xa[y0:y1, x0:x1]).max(), np.abs(got[1] - inc[y0:y1, x0:x1]).max())
+            assert np.abs(got[0] - xa[y0:y1, x0:x1]).max() <= tol and np.abs(got[1] - inc[y0:y1, x0:x1]).max() <= tol, (sp, ti)
+        print(f"{sp}: worst tile difference {worst / np.abs(p.Xa).max():.2e} of the field scale")
+    batch.close()

@@ -249,6 +249,60 @@ def test_a_failing_rank_stops_every_rank_instead_of_hanging_the_gather():
     assert max(g["seconds"] for g in got.values()) < 20
 
 
+def _species_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # BASELINE configs[4]: (species x tile) units -- three species' months cut into tiles of different sizes, weighted by
+        # obs^3; each unit's result is tagged with its species and tile so that a unit landing in the wrong place shows
+        species = ("NO2", "HCHO", "O3")
+        units = [(sp, ti) for sp in species for ti in range(7)]
+        nobs = {u: 300 + 97 * ((3 * i) % 11) for i, u in enumerate(units)}
+        shapes = {u: (2, 3 + u[1] % 3, 4 + (u[1] * 2) % 5) for u in units}
+        weights = [float(nobs[u]) ** 3 for u in units]
+        ran = []
+
+        def analyse(u):
+            ran.append(u)
+            sp, ti = u
+            return torch.full(shapes[u], 1000.0 * species.index(sp) + ti, dtype=torch.float32)
+
+        res = parallel.analyse_units(units, analyse, weights=weights, result_shape=lambda u: shapes[u], dtype=torch.float32)
+        parts = parallel.partition_units(len(units), world, weights)
+        ok = sorted(ran) == sorted(units[i] for i in parts[rank]) and [units[i] for i in parts[rank]] == ran     # its LPT shard, heaviest first
+        loads = [sum(weights[i] for i in part) for part in parts]
+        ok = ok and max(loads) / (sum(loads) / world) < 1.1
+        if rank == 0:
+            for i, u in enumerate(units):
+                sp, ti = u
+                ok = ok and tuple(res[i].shape) == shapes[u] and bool((res[i] == 1000.0 * species.index(sp) + ti).all())
+            ok = ok and {u[0] for u in ran} != set()      # (which species a rank sees is the partition's business)
+        else:
+            ok = ok and res is None
+        q.put((rank, bool(ok), sorted({u[0] for u in ran})))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_species_tile_units_shard_over_two_ranks():
+    """BASELINE configs[4] -- the NO2 / HCHO / O3 months as (species x tile) units through the same
+    partition / one-gather path as config 4 (run/control_omino2.yml:23, control_omihcho.yml, control_omio3.yml): world
+    size 2 over gloo, ragged tiles, every unit back on rank 0 in unit order with its own species' values."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_species_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    got = [q.get(timeout=10) for _ in range(2)]
+    assert all(g[1] for g in got), got
+    assert set(got[0][2]) | set(got[1][2]) == {"NO2", "HCHO", "O3"}
+
+
 def test_shards_come_back_heaviest_first_and_ragged_results_gather():
     w = [3.0, 9.0, 1.0, 27.0, 2.0]
     parts = parallel.partition_units(5, 2, w)
