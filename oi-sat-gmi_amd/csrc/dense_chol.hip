@@ -1364,7 +1364,10 @@ __device__ __forceinline__ bool wait_payload(const double* src, double* vec, Trs
 // then fetched one agent-scope round trip after the other instead of while waiting for its turn -- measured at 4 rows per
 // workgroup: 0.54 vs 0.25 ms per sweep at 10,000 observations, a localised month 73.3 vs 69.6 ms.
 // one block row of a sweep: claim order tk (0 .. nb-1) of ITS system; false = a producer never showed up (bounded spin)
-template <int TRANSPOSE>
+// DAG: the row is a task of the task-graph launch (dense_dag.inc) -- the vectors are then shared with workgroups of the SAME
+// launch across sweeps, so every store to them is an agent-scope (write-through) store and every load of a word another
+// workgroup wrote an agent-scope load (cdna_hip_programming.md Guideline 16); between launches plain accesses do.
+template <int TRANSPOSE, bool DAG>
 __device__ __forceinline__ bool trsv_row(const float* __restrict__ L, int64_t ld, const float* __restrict__ tinv, int nb, int tk,
                                          double* __restrict__ rhs, double* __restrict__ sol, TrsvCtl* __restrict__ ctl,
                                          unsigned* __restrict__ err_total, int two_tiles, double* __restrict__ zout, int64_t m,
@@ -1378,8 +1381,14 @@ __device__ __forceinline__ bool trsv_row(const float* __restrict__ L, int64_t ld
     if (hf == 0) {
         // my block of the right-hand side is read by nobody else: take it and leave the "not yet published" pattern
         // behind, so that the NEXT sweep (which publishes its solution into this vector) finds it prepared
-        acc = rhs[(int64_t)b * NB + row];
-        reinterpret_cast<unsigned long long*>(rhs)[(int64_t)b * NB + row] = kTrsvEmpty;
+        if (DAG) {
+            acc = __hip_atomic_load(&rhs[(int64_t)b * NB + row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(rhs) + (int64_t)b * NB + row, kTrsvEmpty, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            acc = rhs[(int64_t)b * NB + row];
+            reinterpret_cast<unsigned long long*>(rhs)[(int64_t)b * NB + row] = kTrsvEmpty;
+        }
     }
     float4 reg[16];
     const int nsteps = tk;                                  // producers: claim orders 0 .. tk-1
@@ -1427,7 +1436,14 @@ __device__ __forceinline__ bool trsv_row(const float* __restrict__ L, int64_t ld
     if (hf == 0) {
         const int64_t i = (int64_t)b * NB + row;
         __hip_atomic_store(&sol[i], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (zout != nullptr && i < m) zout[i] = accumulate ? zout[i] + acc : acc;       // the solve's result where the caller wants it
+        if (zout != nullptr && i < m) {                     // the solve's result where the caller wants it
+            if (DAG) {
+                const double zi = accumulate ? __hip_atomic_load(&zout[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + acc : acc;
+                __hip_atomic_store(&zout[i], zi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                zout[i] = accumulate ? zout[i] + acc : acc;
+            }
+        }
     }
     return true;
 }
@@ -1462,7 +1478,7 @@ __global__ __launch_bounds__(256) void trsv_pipe_kernel(const float* __restrict_
         __syncthreads();
         const int tk = (int)s_ticket;                    // 0 .. nb-1 in claim order
         if (tk >= nb) break;
-        if (!trsv_row<TRANSPOSE>(L, ld, tinv, nb, tk, rhs, sol, ctl, err_total, two_tiles, zout, m, accumulate, tile, vec, part, &s_ok))
+        if (!trsv_row<TRANSPOSE, false>(L, ld, tinv, nb, tk, rhs, sol, ctl, err_total, two_tiles, zout, m, accumulate, tile, vec, part, &s_ok))
             break;
     }
     if (tid == 0) trsv_leave(ctl);
@@ -1496,7 +1512,7 @@ __global__ __launch_bounds__(256) void trsv_batched_kernel(const SolveMember* __
         if (!first_solve && mb->st->conv != 0) continue;             // this system needs no further correction
         double* in = TRANSPOSE ? mb->fwd : mb->rhs;
         double* out = TRANSPOSE ? mb->rhs : mb->fwd;
-        if (!trsv_row<TRANSPOSE>(mb->S, mb->ld, mb->tinv, mb->mpb, tk, in, out, ctl, err_total, 0, TRANSPOSE ? mb->z : (double*)nullptr,
+        if (!trsv_row<TRANSPOSE, false>(mb->S, mb->ld, mb->tinv, mb->mpb, tk, in, out, ctl, err_total, 0, TRANSPOSE ? mb->z : (double*)nullptr,
                                  mb->m, accumulate, tile, vec, part, &s_ok))
             break;
     }
@@ -2150,6 +2166,7 @@ hipError_t dense_kernel_attributes() {
     return attr_rc;
 }
 
+#include "dense_solve_dev.inc"
 #include "dense_dag.inc"
 
 // Which factorizations run as a task graph: every system / batch of at least three block rows (below that there is nothing to
@@ -2168,13 +2185,22 @@ static inline bool dag_wanted(const oisat_ctx* h, int64_t max_blocks, int nsys) 
 
 void oisat_dag_plan_release(void* plan) { dag_plan_free((DagPlan*)plan); }
 
-extern "C" int oisat_dag_task_order(int nsys, const int32_t* block_rows, int wave, int32_t* tasks_out, int64_t capacity,
-                                    int64_t* ntasks_out, int32_t* reserve_out, int32_t* max_wave_chains_out) {
+extern "C" int oisat_dag_task_order(int nsys, const int32_t* block_rows, int wave, int refine, const int32_t* res_blocks,
+                                    const int32_t* inc_patches, int32_t* tasks_out, int64_t capacity, int64_t* ntasks_out,
+                                    int32_t* reserve_out, int32_t* max_wave_chains_out) {
     ARG_CHECK(nsys > 0 && block_rows && ntasks_out && (tasks_out || capacity == 0));
+    ARG_CHECK(refine >= -1 && refine <= DAG_MAX_REFINE && (refine < 0 || (res_blocks && inc_patches)));
     std::vector<int> nb_of(block_rows, block_rows + nsys);
     for (int s = 0; s < nsys; ++s) ARG_CHECK(nb_of[s] >= 1 && (s == 0 || nb_of[s] <= nb_of[s - 1]));
+    DagSolveShape shape;
+    shape.refine = refine;
+    if (refine >= 0) {
+        shape.nres.assign(res_blocks, res_blocks + nsys);
+        shape.ninc.assign(inc_patches, inc_patches + nsys);
+        for (int s = 0; s < nsys; ++s) ARG_CHECK(shape.nres[s] >= 1 && shape.ninc[s] >= 1);
+    }
     DagOrder order;
-    dag_task_order(nb_of, wave, order);
+    dag_task_order(nb_of, wave, shape, order);
     *ntasks_out = (int64_t)order.tasks.size();
     if (reserve_out) *reserve_out = order.reserve_chains;
     if (max_wave_chains_out) *max_wave_chains_out = order.max_wave_chains;
@@ -2536,7 +2562,7 @@ extern "C" int oisat_batch_create(oisat_ctx* h, int nmat, float* const* S, const
         std::vector<int> nb_of(nmat);
         for (int i = 0; i < nmat; ++i) nb_of[i] = bt->table[i].mpb;
         DagOrder probe;
-        dag_task_order(nb_of, 0, probe);
+        dag_task_order(nb_of, 0, DagSolveShape(), probe);
         want_dag = dag_fits(probe.max_wave_chains, dag_slots(h));        // no: the batch keeps the lock-step recursion
     }
     if (want_dag) {
@@ -2571,6 +2597,7 @@ extern "C" int oisat_batch_destroy(oisat_ctx* h, int batch_id) {
     if (bt->ord_dev) HIP_TRY(hipFree(bt->ord_dev));
     if (bt->ctl_dev) HIP_TRY(hipFree(bt->ctl_dev));
     oisat_dag_plan_release(bt->dag);
+    oisat_dag_plan_release(bt->dag_solve);
     delete bt;
     h->batches[batch_id] = nullptr;
     return OISAT_OK;
@@ -2625,6 +2652,8 @@ extern "C" int oisat_batch_set_solve(oisat_ctx* h, int batch_id, int nmat, const
     HIP_TRY(hipMemcpy(bt->ord_dev, ord.data(), sizeof(int) * ord.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(bt->ctl_dev, 0, 2 * kCtlBytes));
     bt->ord_total = (int)ord.size();
+    oisat_dag_plan_release(bt->dag_solve);
+    bt->dag_solve = nullptr;
     return OISAT_OK;
 }
 
@@ -2645,6 +2674,8 @@ extern "C" int oisat_batch_set_grid(oisat_ctx* h, int batch_id, int nmat, const 
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpy(bt->solve_dev, bt->solve_host.data(), sizeof(SolveMember) * nmat, hipMemcpyHostToDevice));
+    oisat_dag_plan_release(bt->dag_solve);                  // (its increment patches depend on the grids' shapes)
+    bt->dag_solve = nullptr;
     return OISAT_OK;
 }
 
@@ -2691,6 +2722,87 @@ extern "C" int oisat_batch_solve(oisat_ctx* h, int batch_id, int dtype, double g
         if (rc) return rc;
     }
     return oisat_apply_increment_batched(h, dtype, mem, bt.solve_host, bt.max_n, g);
+}
+
+extern "C" int oisat_batch_is_task_graph(oisat_ctx* h, int batch_id, int* yes_out) {
+    ARG_CHECK(h && yes_out && batch_id >= 0 && batch_id < (int)h->batches.size() && h->batches[batch_id]);
+    *yes_out = h->batches[batch_id]->dag != nullptr ? 1 : 0;
+    return OISAT_OK;
+}
+
+// Factorization AND solve phase of every member as ONE task-graph launch (dense_dag.inc "The solve phase as tasks"): what
+// oisat_batch_potrf + oisat_batch_solve do in 2 + 3 (refine + 2) launches with the solve phase exposed behind the
+// factorization.  Same arithmetic per member.  Needs a batch whose factorization runs as a task graph (OISAT_ENOTSUP_DAG
+// otherwise: the caller keeps the two calls).
+extern "C" int oisat_batch_analyse(oisat_ctx* h, int batch_id, int dtype, double g, int refine, int* info_host) {
+    ARG_CHECK(h && batch_id >= 0 && batch_id < (int)h->batches.size() && h->batches[batch_id]);
+    ChBatch& bt = *h->batches[batch_id];
+    ARG_CHECK(bt.solve_dev != nullptr && bt.ord_total > 0 && refine >= 0 && refine <= DAG_MAX_REFINE && g >= 0.0);
+    ARG_CHECK(dtype == OISAT_F32 || dtype == OISAT_F64);
+    if (!bt.dag) {
+        oisat_set_error("oisat_batch_analyse: this batch's factorization does not run as a task graph (oisat_set_task_graph / size)");
+        return OISAT_EINVAL;
+    }
+    int* info_dev = nullptr;
+    char* base = nullptr;
+    if (int rc = status_ws(h, &info_dev, &base)) return rc;
+    HIP_TRY(dense_kernel_attributes());
+    const int nmem = (int)bt.table.size();
+    const double g2 = g * (double)kLog2e;
+    DagSolve sv;
+    sv.mem = bt.solve_dev;
+    sv.g = g;
+    sv.g2 = g2;
+    sv.win_deg = lat_window_deg(g2);
+    sv.cut_chord = cut_chord_of(g2);
+    sv.tol2 = h->refine_tol * h->refine_tol;
+    sv.refine = refine;
+    sv.dtype = dtype;
+    sv.cells = increment_cells(h->cu_count, bt.max_n, nmem);
+    sv.blocks = residual_blocks_pay(g2) ? 1 : 0;
+    for (const SolveMember& sm : bt.solve_host) sv.blocks = sv.blocks && sm.perm != nullptr;
+    sv.trsv_timeouts = (unsigned*)base;
+    if (!bt.dag_solve || bt.dag_solve_refine != refine || bt.dag_solve_cells != sv.cells) {
+        HIP_TRY(hipStreamSynchronize(h->stream));            // (a plan is never freed under a running launch)
+        oisat_dag_plan_release(bt.dag_solve);
+        bt.dag_solve = nullptr;
+        DagSolveShape shape;
+        shape.refine = refine;
+        for (const SolveMember& sm : bt.solve_host) {
+            shape.nres.push_back((int)cdiv(sm.m, 64));
+            shape.ninc.push_back((int)increment_blocks(sm.n, sm.nx, sv.cells));
+        }
+        bt.dag_solve = dag_plan_create(bt.table, h->stream, shape);
+        if (!bt.dag_solve) return OISAT_ENOMEM;
+        HIP_TRY(hipStreamSynchronize(h->stream));            // (the plan's words are zero before any stream can launch it)
+        bt.dag_solve_refine = refine;
+        bt.dag_solve_cells = sv.cells;
+    }
+    HIP_TRY(hipMemsetAsync(info_dev, 0, sizeof(int), h->stream));
+    HIP_TRY(hipMemsetAsync(info_dev + 3, 0, sizeof(int), h->stream));
+    OISAT_LAUNCH(h, "pad_identity", pad_identity_batched_kernel, dim3(32, (unsigned)nmem), dim3(256), 0, (const BatchMat*)bt.table_dev);
+    OISAT_LAUNCH(h, "copy_pad", solve_prep_batched_kernel, dim3((unsigned)stream_grid(bt.max_mp, 256) > 64u ? 64u : (unsigned)stream_grid(bt.max_mp, 256), (unsigned)nmem),
+                 dim3(256), 0, (const SolveMember*)bt.solve_dev);
+    if (int rc = dag_launch(h, *(DagPlan*)bt.dag_solve, info_dev, (unsigned*)(info_dev + kInfoDagTimeouts), &sv)) return rc;
+    if (info_host) {
+        int* pin = (int*)oisat_pinned(h, 64);
+        if (!pin) return OISAT_ENOMEM;
+        HIP_TRY(hipMemcpyAsync(pin, info_dev, 8 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        info_host[0] = pin[0];
+        info_host[1] = pin[0] ? bt.order[pin[3] - 1] : -1;          // the caller's matrix index
+        if (pin[kInfoDagTimeouts] != 0) {
+            HIP_TRY(hipMemsetAsync(info_dev + kInfoDagTimeouts, 0, sizeof(int), h->stream));
+            oisat_set_error("batched analysis: the task-graph launch timed out (a workgroup gave up waiting): factors and fields are incomplete");
+            return OISAT_EHIP;
+        }
+        if (pin[0] != 0) {
+            HIP_TRY(hipMemsetAsync(info_dev + 1, 0, 2 * sizeof(int), h->stream));
+            oisat_set_error("batched potrf: matrix %d not positive definite at column %d", info_host[1], pin[0]);
+            return OISAT_ENOTPD;
+        }
+    }
+    return OISAT_OK;
 }
 
 extern "C" int oisat_batch_potrf(oisat_ctx* h, int batch_id, int* info_host) {

@@ -90,6 +90,8 @@ struct ChBatch {                 // matrices factored in lock-step by oisat_batc
     int64_t max_m = 0, max_n = 0, max_mp = 0;
     bool pairs = false;          // leaves of its recursion are pairs of block columns (many members: the leaf launches are HBM-bound)
     void* dag = nullptr;         // task-graph plan of the batch (dense_dag.inc: DagPlan), owned
+    void* dag_solve = nullptr;   // ... of the batch's factorization + solve phase in one launch (oisat_batch_analyse), made on first use
+    int dag_solve_refine = -1, dag_solve_cells = 0;             // what that plan was made for
 };
 
 struct DagSingle {               // a cached single-system task-graph plan (oisat_potrf)

@@ -364,6 +364,9 @@ class BatchedFactor:
         # behind its factorization (oisat_batch_solve); 0: round 2's form -- the host waits for the group and enqueues every
         # plan's solve on its lane
         self.batched_solve = os.environ.get("OISAT_BATCH_SOLVE", "1") != "0" and all(p.work is not None for p in every)
+        # ... and with the task graph the solve phase is part of the factorization's launch (oisat_batch_analyse; OISAT_DAG_SOLVE=0
+        # keeps the lock-step solve launches behind the factorization launch: the tests compare the two)
+        self.one_launch = self.dag and self.batched_solve and os.environ.get("OISAT_DAG_SOLVE", "1") != "0"
         self.order = os.environ.get("OISAT_BATCH_ORDER", "largest")
         self.groups = groups if self.order == "largest" else groups[::-1]
         # schedule (OISAT_BATCH_SCHEDULE): "overlap" (default) -- one stream per group, all groups side by side;
@@ -396,6 +399,9 @@ class BatchedFactor:
             bid = C.c_int(-1)
             ctx.check(ctx.lib.oisat_batch_create(ctx.h, n, Sp, mm, ld, Tp, C.byref(bid)))
             self.ids.append(bid.value)
+            yes = C.c_int(0)
+            ctx.check(ctx.lib.oisat_batch_is_task_graph(ctx.h, bid.value, C.byref(yes)))
+            self.one_launch = self.one_launch and bool(yes.value)      # (the library may have kept the recursion: too many chains for the CUs)
             if self.batched_solve:                          # the solve phase in lock-step too: tell the batch where everything lives
                 item = g[0].dt.itemsize
                 arr = lambda vals: (C.c_void_p * n)(*vals)      # noqa: E731
@@ -431,6 +437,12 @@ class BatchedFactor:
             if sequential and gi > 0:
                 ctx.wait_for(self.ctxs[gi - 1])             # one parked queue
             info = (C.c_int * 2)(0, -1)
+            if self.one_launch:
+                # factorization, gain solves and increments of the whole group as tasks of ONE persistent launch: the solves of
+                # the systems factored first run underneath the factorization of the others (csrc/dense_dag.inc)
+                ctx.check(ctx.lib.oisat_set_refine_tol(ctx.h, REFINE_TOL))
+                ctx.check(ctx.lib.oisat_batch_analyse(ctx.h, bid, g[0].code, g[0]._g, int(refine), info if check_pd else None))
+                return
             ctx.check(ctx.lib.oisat_batch_potrf(ctx.h, bid, info if check_pd else None))
             if self.batched_solve:
                 ctx.check(ctx.lib.oisat_set_refine_tol(ctx.h, REFINE_TOL))

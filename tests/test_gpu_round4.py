@@ -366,3 +366,37 @@ def test_config5_species_tile_units_at_full_size_on_one_gpu(ctx):
             assert np.abs(got[0] - xa[y0:y1, x0:x1]).max() <= tol and np.abs(got[1] - inc[y0:y1, x0:x1]).max() <= tol, (sp, ti)
         print(f"{sp}: worst tile difference {worst / np.abs(p.Xa).max():.2e} of the field scale")
     batch.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# factorization AND solve phase of a batch as ONE task-graph launch (oisat_batch_analyse)
+# ------------------------------------------------------------------------------------------------
+def _tiled_fields(p, L, refine, monkeypatch, one_launch, dtype=np.float32, tile_deg=30.0, streams=4):
+    monkeypatch.setenv("OISAT_DAG_SOLVE", "1" if one_launch else "0")
+    ta = dense.TiledAnalysis(p.lat, p.lon, tile_deg=tile_deg, halo_km=3 * L, dtype=dtype, streams=streams)
+    ta.load(p.Xa, p.Sa, p.obs_lat, p.obs_lon, p.obs_y, p.obs_var)
+    assert ta.factor.one_launch == one_launch
+    ta.run(L, refine=refine, check_pd=True)
+    ta.run(L, refine=refine)                                          # the unchecked, asynchronous form; progress words handed back clean
+    xa, inc = ta.download()
+    zs = [pl.download_z() for pl in ta.plans if pl is not None]
+    ta.close()
+    return xa, inc, zs
+
+
+@pytest.mark.parametrize("grid,m,L,refine,dtype", [((90, 180), 6000, 350.0, 2, np.float32), ((72, 144), 2500, 500.0, 1, np.float64),
+                                                   ((90, 180), 4000, 300.0, 0, np.float32), ((120, 240), 9000, 250.0, 3, np.float32)])
+def test_one_launch_analysis_equals_factorization_then_lock_step_solve(ctx, monkeypatch, grid, m, L, refine, dtype):
+    """oisat_batch_analyse -- sweeps, float64 residuals, convergence test and increment as tasks of the factorization's
+    launch -- against oisat_batch_potrf followed by oisat_batch_solve (one launch per step for all systems): per system the
+    same device functions in the same order, so the solution vectors and the fields are the same BITS; with the compact-block
+    residual (L <= 340 km) and the latitude-row one, float32 and float64 fields, refine 0 .. 3 (rounds skipped after
+    convergence included)."""
+    p = syn.point_obs_case(grid[0], grid[1], m, 9600 + m, swaths=True)
+    xa1, inc1, z1 = _tiled_fields(p, L, refine, monkeypatch, True, dtype)
+    xa0, inc0, z0 = _tiled_fields(p, L, refine, monkeypatch, False, dtype)
+    assert np.isfinite(xa1).all() and np.abs(inc1).max() > 0
+    for a, b in zip(z1, z0):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(inc1, inc0)
+    np.testing.assert_array_equal(xa1, xa0)
