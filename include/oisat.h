@@ -367,20 +367,16 @@ int oisat_gain_diag(oisat_ctx* h, const float* L, int64_t m, int64_t ld, const d
                     double* ak_out);
 
 /* The ticket list of a task-graph launch over nsys systems of block_rows[s] block rows (largest first), as the library would
- * build it -- host only, no device: int32 quadruples (kind, system, a, b) with kind 0 = chain of `system` (a = first row of its
- * trace stamps), 1 = tile task T(a, b), 2 = SUB(b) (tile (b+1, b)), 3 = PRE(b) (tile (b, b)); and, when refine >= 0 (the list
- * of oisat_batch_analyse: factorization and solve phase in one launch; res_blocks[s] = ceil(m_s / 64), inc_patches[s] = the
- * increment's workgroups of system s), 5 = row of a forward sweep (a = block row, b = refinement round), 6 = row of a
- * backward sweep (a = claim order: block row nb-1-a), 7 = block a of residual evaluation b, 8 = increment patch a.
- * refine = -1: factorization only (the two arrays may be NULL).  wave <= 0: the default (eight systems per wave behind wave 0).
- * capacity = 0 just counts.  max_wave_chains_out (may be NULL): the chain tickets that can be resident at one time (the
- * largest wave's and the next one's) -- a launch is only made when four times that many workgroups are resident (each
- * chain holds one and waits for tasks that the others must draw); otherwise the factorization keeps the lock-step
- * recursion.  For tests of the scheduling rule (every input of a task carries a lower ticket, or is its system's chain)
- * and of that bound. */
-int oisat_dag_task_order(int nsys, const int32_t* block_rows, int wave, int refine, const int32_t* res_blocks,
-                         const int32_t* inc_patches, int32_t* tasks_out, int64_t capacity, int64_t* ntasks_out,
-                         int32_t* reserve_out, int32_t* max_wave_chains_out);
+ * build it -- host only, no device: int32 quadruples (kind, system, i, j) with kind 0 = chain of `system` (i = first row of its
+ * trace stamps), 1 = tile task T(i, j), 2 = SUB(j) (tile (j+1, j)), 3 = PRE(j) (tile (j, j)).  (The solve tasks of
+ * oisat_batch_analyse are not tickets: they enter the launch's ready queue when their input is complete.)  wave <= 0: the
+ * default (eight systems per wave behind wave 0).  capacity = 0 just counts.  max_wave_chains_out (may be NULL): the chain
+ * tickets that can be resident at one time (the largest wave's and the next one's) -- a launch is only made when four times
+ * that many workgroups are resident (each chain holds one and waits for tasks that the others must draw); otherwise the
+ * factorization keeps the lock-step recursion.  For tests of the scheduling rule (every input of a task carries a lower
+ * ticket, or is its system's chain) and of that bound. */
+int oisat_dag_task_order(int nsys, const int32_t* block_rows, int wave, int32_t* tasks_out, int64_t capacity,
+                         int64_t* ntasks_out, int32_t* reserve_out, int32_t* max_wave_chains_out);
 
 /* Schedule of the factorizations this handle runs from now on (oisat_potrf, batches made by oisat_batch_create): 1 = the
  * task graph (ONE persistent launch of left-looking tile tasks, csrc/dense_dag.inc) wherever it applies, 0 = the recursion
@@ -441,8 +437,9 @@ int oisat_batch_set_solve(oisat_ctx* h, int batch_id, int nmat, const double* co
 int oisat_batch_set_grid(oisat_ctx* h, int batch_id, int nmat, const int64_t* nx, const int32_t* const* perm);
 int oisat_batch_solve(oisat_ctx* h, int batch_id, int dtype, double g, int refine);
 /* oisat_batch_potrf + oisat_batch_solve as ONE task-graph launch: every member's factorization, gain solve (sweeps, float64
- * residuals, convergence test, at most `refine` corrections) and increment are tasks of one persistent launch, so the solves
- * of the systems that are factored first run underneath the factorization of the others instead of behind the whole batch
+ * residuals, convergence test, at most `refine` corrections) and increment are tasks of one persistent launch -- put into its
+ * ready queue by the task that completes their input -- so the solves of the systems that are factored first run underneath
+ * the factorization of the others instead of behind the whole batch
  * (a localised 720x1440 month: the solve phase was 12 of 62 ms with idle MFMA pipes).  Per member the same arithmetic as the
  * two calls.  Needs oisat_batch_set_solve (and oisat_batch_set_grid) and a batch whose factorization runs as a task graph
  * (oisat_set_task_graph; OISAT_EINVAL otherwise -- use the two calls).  info_host as in oisat_batch_potrf (NULL: unchecked,
@@ -479,7 +476,8 @@ int oisat_comm_destroy(oisat_ctx* h);
  *                                   NaN fill pattern)
  *   OISAT_STATUS_UNCONVERGED        gain solves (oisat_gain_solve, members of oisat_batch_solve / oisat_batch_analyse) that took
  *                                   every one of their `refine` corrections and whose float64 residual |d - S z| was still above
- *                                   tol |d| behind the last one (oisat_set_refine_tol; tol = 0 never counts): z is the best
+ *                                   tol |d| behind the last one (oisat_set_refine_tol; tol = 0 and refine = 0 -- the plain
+ *                                   solve, no residual is formed -- never count): z is the best
  *                                   iterate, NOT within the tolerance -- the exact gain of optimal_interpolation.py:27 is what
  *                                   the 1e-5 bar is measured against, so a caller must not take such fields for converged ones
  *   OISAT_STATUS_UNCONVERGED_MEMBER the caller's index (oisat_batch_create order) of the first such batch member; -1 = none,

@@ -2185,22 +2185,13 @@ static inline bool dag_wanted(const oisat_ctx* h, int64_t max_blocks, int nsys) 
 
 void oisat_dag_plan_release(void* plan) { dag_plan_free((DagPlan*)plan); }
 
-extern "C" int oisat_dag_task_order(int nsys, const int32_t* block_rows, int wave, int refine, const int32_t* res_blocks,
-                                    const int32_t* inc_patches, int32_t* tasks_out, int64_t capacity, int64_t* ntasks_out,
-                                    int32_t* reserve_out, int32_t* max_wave_chains_out) {
+extern "C" int oisat_dag_task_order(int nsys, const int32_t* block_rows, int wave, int32_t* tasks_out, int64_t capacity,
+                                    int64_t* ntasks_out, int32_t* reserve_out, int32_t* max_wave_chains_out) {
     ARG_CHECK(nsys > 0 && block_rows && ntasks_out && (tasks_out || capacity == 0));
-    ARG_CHECK(refine >= -1 && refine <= DAG_MAX_REFINE && (refine < 0 || (res_blocks && inc_patches)));
     std::vector<int> nb_of(block_rows, block_rows + nsys);
     for (int s = 0; s < nsys; ++s) ARG_CHECK(nb_of[s] >= 1 && (s == 0 || nb_of[s] <= nb_of[s - 1]));
-    DagSolveShape shape;
-    shape.refine = refine;
-    if (refine >= 0) {
-        shape.nres.assign(res_blocks, res_blocks + nsys);
-        shape.ninc.assign(inc_patches, inc_patches + nsys);
-        for (int s = 0; s < nsys; ++s) ARG_CHECK(shape.nres[s] >= 1 && shape.ninc[s] >= 1);
-    }
     DagOrder order;
-    dag_task_order(nb_of, wave, shape, order);
+    dag_task_order(nb_of, wave, order);
     *ntasks_out = (int64_t)order.tasks.size();
     if (reserve_out) *reserve_out = order.reserve_chains;
     if (max_wave_chains_out) *max_wave_chains_out = order.max_wave_chains;
@@ -2368,11 +2359,12 @@ extern "C" int oisat_gain_solve(oisat_ctx* h, const float* L, const double* oxyz
     // that is still above the tolerance there is recorded in the handle's status (oisat_solve_status_ex)
     int* info_dev = nullptr;
     if (int rs = status_ws(h, &info_dev, nullptr)) return rs;
-    for (int it = 0; it <= refine; ++it) {
+    // (refine = 0 asks for the plain solve: no residual is formed -- unless the caller wants it reported -- and nothing is flagged)
+    for (int it = 0; it <= refine && (refine > 0 || resid_host); ++it) {
         rc = oisat_cov_residual_if(h, oxyz, osig, ovar, m, g, d, z_out, rhs, olat_sorted, &st->conv, perm);
         if (rc) return rc;
         OISAT_LAUNCH(h, "resid_check", resid_check_kernel, dim3(1), dim3(1024), 0, (const double*)rhs, d, m, it, tol * tol, st,
-                     it == refine ? 1 : 0, info_dev);
+                     it == refine && refine > 0 ? 1 : 0, info_dev);
         if (it == refine) break;
         rc = trsv_solve(h, h->factor, rhs, fwd, st, z_out, 1);
         if (rc) return rc;
@@ -2562,7 +2554,7 @@ extern "C" int oisat_batch_create(oisat_ctx* h, int nmat, float* const* S, const
         std::vector<int> nb_of(nmat);
         for (int i = 0; i < nmat; ++i) nb_of[i] = bt->table[i].mpb;
         DagOrder probe;
-        dag_task_order(nb_of, 0, DagSolveShape(), probe);
+        dag_task_order(nb_of, 0, probe);
         want_dag = dag_fits(probe.max_wave_chains, dag_slots(h));        // no: the batch keeps the lock-step recursion
     }
     if (want_dag) {
@@ -2712,7 +2704,7 @@ extern "C" int oisat_batch_solve(oisat_ctx* h, int batch_id, int dtype, double g
     if (rc) return rc;
     int* info_dev = nullptr;
     if (int rs = status_ws(h, &info_dev, nullptr)) return rs;
-    for (int it = 0; it <= refine; ++it) {                  // (the last evaluation only runs for members that are still above the tolerance)
+    for (int it = 0; it <= refine && refine > 0; ++it) {    // (the last evaluation only runs for members that are still above the tolerance)
         rc = oisat_cov_residual_batched(h, mem, bt.solve_host, bt.max_m, g);
         if (rc) return rc;
         OISAT_LAUNCH(h, "resid_check", resid_check_batched_kernel, dim3((unsigned)nmem), dim3(1024), 0, mem, it, tol * tol,
@@ -2762,6 +2754,7 @@ extern "C" int oisat_batch_analyse(oisat_ctx* h, int batch_id, int dtype, double
     sv.blocks = residual_blocks_pay(g2) ? 1 : 0;
     for (const SolveMember& sm : bt.solve_host) sv.blocks = sv.blocks && sm.perm != nullptr;
     sv.trsv_timeouts = (unsigned*)base;
+    sv.nsys = nmem;
     if (!bt.dag_solve || bt.dag_solve_refine != refine || bt.dag_solve_cells != sv.cells) {
         HIP_TRY(hipStreamSynchronize(h->stream));            // (a plan is never freed under a running launch)
         oisat_dag_plan_release(bt.dag_solve);
@@ -2778,6 +2771,8 @@ extern "C" int oisat_batch_analyse(oisat_ctx* h, int batch_id, int dtype, double
         bt.dag_solve_refine = refine;
         bt.dag_solve_cells = sv.cells;
     }
+    sv.queue = ((DagPlan*)bt.dag_solve)->queue_dev;
+    sv.qcap = (int)((DagPlan*)bt.dag_solve)->qcap;
     HIP_TRY(hipMemsetAsync(info_dev, 0, sizeof(int), h->stream));
     HIP_TRY(hipMemsetAsync(info_dev + 3, 0, sizeof(int), h->stream));
     OISAT_LAUNCH(h, "pad_identity", pad_identity_batched_kernel, dim3(32, (unsigned)nmem), dim3(256), 0, (const BatchMat*)bt.table_dev);

@@ -102,8 +102,7 @@ SIGNATURES = {
     "oisat_batch_potrf": (C.c_int, [_c_ctx, C.c_int, C.POINTER(C.c_int)]),
     "oisat_batch_set_solve": (C.c_int, [_c_ctx, C.c_int, C.c_int] + [C.POINTER(_ptr)] * 11 + [C.POINTER(_i64)] + [C.POINTER(_ptr)] * 3),
     "oisat_set_task_graph": (C.c_int, [_c_ctx, C.c_int]),
-    "oisat_dag_task_order": (C.c_int, [C.c_int, _ptr, C.c_int, C.c_int, _ptr, _ptr, _ptr, _i64, C.POINTER(_i64), C.POINTER(C.c_int),
-                                       C.POINTER(C.c_int)]),
+    "oisat_dag_task_order": (C.c_int, [C.c_int, _ptr, C.c_int, _ptr, _i64, C.POINTER(_i64), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "oisat_batch_set_grid": (C.c_int, [_c_ctx, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(_ptr)]),
     "oisat_set_obs_blocks": (C.c_int, [_c_ctx, _ptr, _i64]),
     "oisat_batch_solve": (C.c_int, [_c_ctx, C.c_int, C.c_int, C.c_double, C.c_int]),

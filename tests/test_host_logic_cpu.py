@@ -180,7 +180,7 @@ def test_tile_partition_polar_caps_and_halo():
 # ------------------------------------------------------------------------------------------------
 # task-graph factorization: the ticket order (csrc/dense_dag.inc), checked on the host
 # ------------------------------------------------------------------------------------------------
-def _dag_order(block_rows, wave=0, refine=-1, res_blocks=None, inc_patches=None):
+def _dag_order(block_rows, wave=0):
     import ctypes as C
     from oisatgmi import _hip
     if not os.path.exists(_hip.library_path()):
@@ -188,17 +188,13 @@ def _dag_order(block_rows, wave=0, refine=-1, res_blocks=None, inc_patches=None)
         g.build()
     lib = C.CDLL(_hip.library_path())
     lib.oisat_dag_task_order.restype = C.c_int
-    lib.oisat_dag_task_order.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
-                                         C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.oisat_dag_task_order.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int),
+                                         C.POINTER(C.c_int)]
     nb = np.asarray(block_rows, dtype=np.int32)
-    nres = np.asarray(res_blocks if res_blocks is not None else [], dtype=np.int32)
-    ninc = np.asarray(inc_patches if inc_patches is not None else [], dtype=np.int32)
-    pr, pi = (nres.ctypes.data, ninc.ctypes.data) if refine >= 0 else (None, None)
     n, res, mwc = C.c_int64(0), C.c_int(0), C.c_int(0)
-    assert lib.oisat_dag_task_order(len(nb), nb.ctypes.data, wave, refine, pr, pi, None, 0, C.byref(n), C.byref(res), C.byref(mwc)) == 0
+    assert lib.oisat_dag_task_order(len(nb), nb.ctypes.data, wave, None, 0, C.byref(n), C.byref(res), C.byref(mwc)) == 0
     out = np.zeros((n.value, 4), dtype=np.int32)
-    assert lib.oisat_dag_task_order(len(nb), nb.ctypes.data, wave, refine, pr, pi, out.ctypes.data, n.value, C.byref(n), C.byref(res),
-                                    C.byref(mwc)) == 0
+    assert lib.oisat_dag_task_order(len(nb), nb.ctypes.data, wave, out.ctypes.data, n.value, C.byref(n), C.byref(res), C.byref(mwc)) == 0
     return out, res.value, mwc.value
 
 
@@ -238,48 +234,6 @@ def test_task_graph_ticket_order_is_topological_and_complete(block_rows, wave):
                     # r == k + 1: the chain's panel tile; r == k cannot happen (k < j <= i)
     # the chains that get a CU to themselves hold the first tickets
     assert all(tasks[t][0] == 0 for t in range(reserve))
-
-
-@pytest.mark.parametrize("block_rows,wave,refine", [(MONTH, 8, 2), ([79], 0, 2), ([17, 12, 11, 8, 7, 5, 3, 3, 2, 1, 1], 2, 1),
-                                                     ([20, 9, 9, 8, 8, 7, 3, 2, 1], 5, 0), ([40] * 20, 8, 3)])
-def test_task_graph_solve_tickets_follow_what_they_wait_for(block_rows, wave, refine):
-    """oisat_batch_analyse: the gain solve and the increment of every system are tasks of the factorization's launch
-    (csrc/dense_dag.inc "The solve phase as tasks").  A solve task waits for its system's factorization and for the EARLIER
-    phases of its own system -- so, for the launch to drain, every solve ticket of a system must come behind every
-    factorization ticket of that system (its chain included) and the phases of a system must be in order: per round FWD rows
-    (ascending), BWD rows, RES blocks, at the end the INC patches.  And the factorization tickets alone are still the
-    factorization-only list, in its order."""
-    rng = np.random.default_rng(len(block_rows))
-    nres = [2 * nb - int(rng.integers(0, 2)) for nb in block_rows]
-    ninc = [int(rng.integers(1, 40)) for _ in block_rows]
-    tasks, reserve, mwc = _dag_order(block_rows, wave, refine, nres, ninc)
-    base, reserve0, mwc0 = _dag_order(block_rows, wave)
-    fact = tasks[tasks[:, 0] <= 3]
-    np.testing.assert_array_equal(fact, base)
-    assert (reserve, mwc) == (reserve0, mwc0) and all(tasks[t][0] == 0 for t in range(reserve))
-    FWD, BWD, RES, INC = 5, 6, 7, 8
-    last_fact = {}
-    seen = {}
-    for t, (kind, s, a, b) in enumerate(tasks.tolist()):
-        if kind <= 3:
-            last_fact[s] = t
-        else:
-            seen.setdefault(s, []).append((t, kind, a, b))
-    assert sorted(seen) == list(range(len(block_rows)))
-    for s, nb in enumerate(block_rows):
-        want = []
-        for r in range(refine + 1):
-            want += [(FWD, k, r) for k in range(nb)] + [(BWD, k, r) for k in range(nb)] + [(RES, k, r) for k in range(nres[s])]
-        want += [(INC, k, 0) for k in range(ninc[s])]
-        got = [(kind, a, b) for (_, kind, a, b) in seen[s]]
-        assert got == want, s                                         # complete, each once, phases and rows in order
-        assert seen[s][0][0] > last_fact[s], s                        # behind the system's last factorization ticket
-    if len(block_rows) > 20:
-        # a month: the solve of every wave but the last rides on later waves' factorization tickets -- only the last wave's
-        # eight systems are left for the tail
-        last_factor_ticket = max(last_fact.values())
-        tail_systems = {s for s in seen if seen[s][-1][0] > last_factor_ticket}
-        assert 0 < len(tail_systems) <= 8 + 8, len(tail_systems)
 
 
 def test_task_graph_chains_must_leave_room_for_the_tasks_they_wait_for():
