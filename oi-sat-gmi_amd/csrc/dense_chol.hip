@@ -2773,6 +2773,7 @@ extern "C" int oisat_batch_analyse(oisat_ctx* h, int batch_id, int dtype, double
     }
     sv.queue = ((DagPlan*)bt.dag_solve)->queue_dev;
     sv.qcap = (int)((DagPlan*)bt.dag_solve)->qcap;
+    sv.qcap0 = (int)((DagPlan*)bt.dag_solve)->qcap0;
     HIP_TRY(hipMemsetAsync(info_dev, 0, sizeof(int), h->stream));
     HIP_TRY(hipMemsetAsync(info_dev + 3, 0, sizeof(int), h->stream));
     OISAT_LAUNCH(h, "pad_identity", pad_identity_batched_kernel, dim3(32, (unsigned)nmem), dim3(256), 0, (const BatchMat*)bt.table_dev);

@@ -364,9 +364,11 @@ class BatchedFactor:
         # behind its factorization (oisat_batch_solve); 0: round 2's form -- the host waits for the group and enqueues every
         # plan's solve on its lane
         self.batched_solve = os.environ.get("OISAT_BATCH_SOLVE", "1") != "0" and all(p.work is not None for p in every)
-        # ... and with the task graph the solve phase is part of the factorization's launch (oisat_batch_analyse; OISAT_DAG_SOLVE=0
-        # keeps the lock-step solve launches behind the factorization launch: the tests compare the two)
-        self.one_launch = self.dag and self.batched_solve and os.environ.get("OISAT_DAG_SOLVE", "1") != "0"
+        # ... or, with the task graph, as tasks of the factorization's own launch (oisat_batch_analyse, OISAT_DAG_SOLVE=1): the
+        # same bits in one launch instead of ~15.  Not the default: it ties for one month (61.5-63 vs 62.6 ms) and loses for
+        # twelve (0.73 vs 0.71 s) -- the launch is bound by workgroup-slot time, and fp64 VALU work does not overlap with the
+        # MFMA K-loop on this chip (csrc/dense_dag.inc "WHAT IT BOUGHT").  The tests run both and compare them bit for bit.
+        self.one_launch = self.dag and self.batched_solve and os.environ.get("OISAT_DAG_SOLVE", "0") == "1"
         self.order = os.environ.get("OISAT_BATCH_ORDER", "largest")
         self.groups = groups if self.order == "largest" else groups[::-1]
         # schedule (OISAT_BATCH_SCHEDULE): "overlap" (default) -- one stream per group, all groups side by side;

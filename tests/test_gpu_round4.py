@@ -54,12 +54,16 @@ def test_unconverged_refinement_is_reported_single_system(ctx):
     plan.check()
 
 
-def test_unconverged_refinement_names_the_batch_member(ctx, monkeypatch):
-    """The lock-step / task-graph batch path (oisat_batch_solve): with a 1e-12 tolerance and one correction every member ends
-    above it; the status counts them and names the first by the CALLER's index; with four corrections the month is clean."""
+@pytest.mark.parametrize("one_launch", [False, True])
+def test_unconverged_refinement_names_the_batch_member(ctx, monkeypatch, one_launch):
+    """The batch paths (oisat_batch_solve: lock-step launches; oisat_batch_analyse: tasks of the factorization's launch): with a
+    1e-12 tolerance and one correction every member ends above it; the status counts them and names the first by the CALLER's
+    index; with five corrections the month is clean."""
+    monkeypatch.setenv("OISAT_DAG_SOLVE", "1" if one_launch else "0")
     p = syn.point_obs_case(90, 180, 5000, 9402, swaths=True)
     ta = dense.TiledAnalysis(p.lat, p.lon, tile_deg=30.0, halo_km=900.0, dtype=np.float32, streams=4)
     ta.load(p.Xa, p.Sa, p.obs_lat, p.obs_lon, p.obs_y, p.obs_var)
+    assert ta.factor.one_launch == one_launch
     monkeypatch.setattr(dense, "REFINE_TOL", 1e-12)
     with pytest.raises(_hip.OisatError, match=r"gain solve\(s\) ended above the refinement tolerance.*first: batch member \d+"):
         ta.run(300.0, refine=1)

@@ -242,10 +242,19 @@ def test_task_graph_chains_must_leave_room_for_the_tasks_they_wait_for():
     one more wave behind wave 0: a wave's chains still walk their last columns when the next wave's are drawn) and only
     launches a task graph on four times as many workgroups; this is that count."""
     assert _dag_order([79])[2] == 1
-    assert _dag_order(MONTH)[2] == 8 + 8                               # two polar caps, then eight tiles at a time
-    assert _dag_order([40] * 100)[2] == 64 + 8                         # wave 0 holds at most 64 chains
-    assert _dag_order([40] * 30, wave=3)[2] == 30                      # all of them within a factor two: one wave
-    assert _dag_order([40, 40] + [10] * 30, wave=20)[2] == 20 + 20
+    assert _dag_order(MONTH)[2] == 8 + 8                               # eight tiles at a time, the two polar caps as a pair among them
+    assert _dag_order([40] * 100)[2] == 8 + 8                          # 64 "big" ones in pairs spread through the waves of the other 36
+    assert _dag_order([40] * 30, wave=3)[2] == 30                      # all of them within a factor two and nothing smaller: one wave
+    assert _dag_order([40, 40] + [10] * 30, wave=20)[2] == 20 + 10
+    # a pair of big systems opens the launch, the others are spread evenly through the small waves (twelve months: 24 caps)
+    tasks, reserve, _ = _dag_order(MONTH, 8)
+    chain_sys = [int(s) for (kind, s, a, b) in tasks.tolist() if kind == 0]
+    assert chain_sys[:2] == [0, 1] and chain_sys[-1] >= 2
+    twelve = sorted(MONTH * 12, reverse=True)
+    tasks, reserve, mwc = _dag_order(twelve, 8)
+    chain_sys = [int(s) for (kind, s, a, b) in tasks.tolist() if kind == 0]
+    pos = [chain_sys.index(b) for b in range(0, 24, 2)]
+    assert pos[0] == 0 and all(40 <= b - a <= 60 for a, b in zip(pos, pos[1:])) and mwc == 16
 
 
 def _run_bench(*argv, env_extra=None):

@@ -34,6 +34,15 @@ def report(path, nseg=20):
         wait = tk[sel, 2] * us if kind != 0 else np.zeros(sel.sum())
         print("%-6s %8d %10.1f %10.1f %10.1f %12.2f %12.2f" % (name, sel.sum(), dur.mean(), wait.mean(), (dur - wait).mean(), dur.sum() * 1e-3,
                                                                 (dur - wait).sum() * 1e-3))
+    # the per-workgroup rows sit behind the chains' rows: those with a plausible task count
+    grid_rows = ch[np.where((ch[:, 3] > 0) & (ch[:, 3] < 10000) & (ch[:, 4] > ch[:, 0]) & (ch[:, 5] == 0))[0]]
+    if len(grid_rows):
+        life = (grid_rows[:, 4] - grid_rows[:, 0]) * us
+        print("per workgroup (%d rows): alive %.1f ms, claiming work %.2f ms (%.1f %%), in tasks %.2f ms (%.1f %%), %.0f tasks"
+              % (len(grid_rows), life.mean() * 1e-3, grid_rows[:, 1].mean() * us * 1e-3, 100 * grid_rows[:, 1].sum() / max(1, (grid_rows[:, 4] - grid_rows[:, 0]).sum()),
+                 grid_rows[:, 2].mean() * us * 1e-3, 100 * grid_rows[:, 2].sum() / max(1, (grid_rows[:, 4] - grid_rows[:, 0]).sum()), grid_rows[:, 3].mean()))
+        print("   of the claiming: looking at / claiming from the queue %.2f ms, waiting for the claimed entry %.2f ms, the rest (ticket counter) %.2f ms"
+              % (grid_rows[:, 6].mean() * us * 1e-3, grid_rows[:, 7].mean() * us * 1e-3, (grid_rows[:, 1] - grid_rows[:, 6] - grid_rows[:, 7]).mean() * us * 1e-3))
     # last factorization ticket finished / first solve ticket started, per wave marker: when does each system's last solve task end
     fact = (tasks[:, 0] <= 3) & ran
     print("last factorization task ends at %.2f ms; last solve task at %.2f ms" % ((tk[fact, 1].max() - t0) * us * 1e-3, span * 1e-3))
