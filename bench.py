@@ -423,6 +423,24 @@ def regrid_leg(ctx, sync):
         dt = time.perf_counter() - t0
         out[f"type{it}_s_per_granule"] = dt
         out[f"type{it}_fields_per_s"] = 73 / dt
+    # a month's loop over granules (reader.py:1405): type 1 with the triangulations of the granules ahead built by host threads
+    # while the device regrids the current one (interpolator_many) -- amortised over 32 granules of that size
+    from oisatgmi.interpolator import interpolator_many
+    many = []
+    for k in range(32):
+        gk = syn.swath_granule(7100 + k, nscan=1644, npix=60, lat0=-70.0, lat1=70.0, lon_c=-170.0 + 10.0 * k, width_deg=24.0)
+        gk.scattering_weights, gk.pressure_mid = g.scattering_weights, g.pressure_mid
+        many.append(gk)
+    with contextlib.redirect_stdout(io.StringIO()):
+        interpolator_many(1, 0.25, many[:2], ctm, 0.75)
+        sync()
+        t0 = time.perf_counter()
+        res = interpolator_many(1, 0.25, many, ctm, 0.75)
+        sync()
+    dt = time.perf_counter() - t0
+    out["type1_many_s_per_granule"] = dt / len(many)
+    out["type1_many"] = {"granules": len(many), "seconds": dt, "regridded": sum(r is not None for r in res), "host_threads": min(8, len(os.sched_getaffinity(0))),
+                         "note": "interpolator_many: qhull for the granules ahead on host threads, device regrid of the current one; outputs bit-identical to the serial calls"}
     return out
 
 

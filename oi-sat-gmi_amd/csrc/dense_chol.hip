@@ -46,17 +46,6 @@ constexpr int LDSW = 36;         // padded LDS row stride in floats (144 B, 16-B
 // observation tile becomes one launch that fills the chip, and the chain of dependent launches is paid once per batch
 // instead of once per tile.  The table is sorted by block count (largest first): the matrices a node applies to are a
 // prefix of it.  Operands are derived in the kernel from (table entry, node), so nothing is uploaded per launch.
-// Wave priority of the dependent-chain kernels (diagonal block, panel TRSM, small updates, triangular sweeps) when they
-// share CUs with another stream's bulk GEMMs (OISAT_CHAIN_PRIO, 0..3; uploaded once by dense_kernel_attributes): the
-// SIMD's instruction arbiter then serves the chain's waves first.
-__device__ int g_chain_prio = 0;
-__device__ __forceinline__ void chain_prio() {
-    const int p = __builtin_amdgcn_readfirstlane(g_chain_prio);
-    if (p == 3) __builtin_amdgcn_s_setprio(3);
-    else if (p == 2) __builtin_amdgcn_s_setprio(2);
-    else if (p == 1) __builtin_amdgcn_s_setprio(1);
-}
-
 struct BatchArgs {
     const BatchMat* mats;        // nullptr: not a batched launch
     int kind;                    // 0: trailing update of node (b0, mid, b1);  1: TRSM of the panel below diagonal block b0
@@ -550,7 +539,6 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(float* C, int64_t ld
                                                              const float* __restrict__ B, int64_t ldb, int ntm, int ntn, int K,
                                                              int mode, int lower, BatchArgs ba) {
     __shared__ __attribute__((aligned(16))) float lds[NBUF][2][SB * LDSW];    // 36,864 B / 18,432 B
-    chain_prio();
     if (BATCH) group_prio(ba.prio);
     if (BATCH) {
         const float* Bb = nullptr;
@@ -641,7 +629,6 @@ __global__ __launch_bounds__(256) void gemm_nt_rows64_kernel(float* C, int64_t l
                                                               const float* __restrict__ B, int64_t ldb, int K, int mode, BatchArgs ba) {
     __shared__ __attribute__((aligned(16))) float ldsA[NBUF][SB * LDSW];     // 18,432 B / 9,216 B
     __shared__ __attribute__((aligned(16))) float ldsB[NBUF][NB * LDSW];     // 36,864 B / 18,432 B  (NBUF = 1: 27,648 B in all)
-    chain_prio();
     if (BATCH) group_prio(ba.prio);
     if (BATCH) {
         int ntm, ntn;
@@ -795,7 +782,6 @@ __global__ __launch_bounds__(256) void pair_panel_kernel(float* __restrict__ S, 
                                                           int b, const BatchMat* __restrict__ mats, int prio) {
     __shared__ __attribute__((aligned(16))) float img[SB * LDP];         // 33,792 B: X1 -> P1 -> X2'
     __shared__ __attribute__((aligned(16))) float ldsB[NB * LDSW];       // 18,432 B
-    chain_prio();
     group_prio(prio);
     if (BATCH) {
         const BatchMat* bm = mats + blockIdx.y;
@@ -891,7 +877,6 @@ __global__ __launch_bounds__(256) void pair_mid_kernel(float* __restrict__ S, in
                                                         const BatchMat* __restrict__ mats, int prio) {
     __shared__ __attribute__((aligned(16))) float img0[SB * LDP], img1[SB * LDP];      // the two 64-row halves of X, then of L21
     __shared__ __attribute__((aligned(16))) float ldsB[NB * LDSW];                     // 67,584 + 18,432 B
-    chain_prio();
     group_prio(prio);
     if (BATCH) {
         const BatchMat* bm = mats + blockIdx.x;
@@ -1263,7 +1248,6 @@ __global__ __launch_bounds__(D3_THREADS, 4) void potrf_diag3_kernel(float* __res
                                                                     int* __restrict__ info, int block_index, const BatchMat* __restrict__ mats,
                                                                     int prio) {
     __shared__ __attribute__((aligned(16))) float Pp[2 * D3_PBUF], Xr[7 * D3_TILE], dinvb[2 * D3_TILE], stage[16 * D3_SLD];
-    chain_prio();
     group_prio(prio);
     if (mats) {                            // batched: workgroup = matrix blockIdx.x of the table (largest first)
         const BatchMat bm = mats[blockIdx.x];
@@ -1467,7 +1451,6 @@ __global__ __launch_bounds__(256) void trsv_pipe_kernel(const float* __restrict_
     __shared__ double vec[NB], part[NB];
     __shared__ unsigned s_ticket, s_ok;
     const int tid = threadIdx.x;
-    chain_prio();
     if (st != nullptr && st->conv != 0) return;          // refinement already converged: this sweep is not needed (block-uniform)
     while (true) {
         __syncthreads();                                 // the previous row's LDS (vec, part, tiles, ticket) is no longer read
@@ -1496,7 +1479,6 @@ __global__ __launch_bounds__(256) void trsv_batched_kernel(const SolveMember* __
     __shared__ double vec[NB], part[NB];
     __shared__ unsigned s_ticket, s_ok;
     const int tid = threadIdx.x;
-    chain_prio();
     while (true) {
         __syncthreads();
         if (tid == 0) {
@@ -1646,13 +1628,12 @@ __global__ __launch_bounds__(256) void gain_diag_kernel(const double* __restrict
     ak[a0 + r] = 1.0 - ovar[a0 + r] * ss[r];         // diag(K H) at the observation: 1 - R_aa (S^-1)_aa
 }
 
-static const int kBigK = getenv("OISAT_GEMM_BIG_K") ? atoi(getenv("OISAT_GEMM_BIG_K")) : 2048;   // K from which gemm_nt_big_kernel is used
+static const int kBigK = 2048;                           // K from which gemm_nt_big_kernel is used (below it the persistent kernel with the C prefetch wins)
 
 // grid of the persistent gemm_nt_kernel: every tile its own workgroup while they all fit (2 per CU), else 2 per CU
 // (a multiple of 8, so that workgroup b keeps its XCD for all of its tiles)
 static inline unsigned persistent_grid(const oisat_ctx* h, int64_t virtual_tiles) {
-    static const int env_per_cu = getenv("OISAT_GEMM_WG_PER_CU") ? atoi(getenv("OISAT_GEMM_WG_PER_CU")) : 2;
-    const int per_cu = h->gemm_wg_per_cu > 0 ? h->gemm_wg_per_cu : env_per_cu;
+    const int per_cu = h->gemm_wg_per_cu > 0 ? h->gemm_wg_per_cu : 2;
     const int64_t slots = ((int64_t)(h->cu_count > 0 ? h->cu_count : 256) * per_cu) / 8 * 8;
     return (unsigned)(virtual_tiles <= slots || per_cu <= 0 ? virtual_tiles : slots);
 }
@@ -1660,8 +1641,6 @@ static inline unsigned persistent_grid(const oisat_ctx* h, int64_t virtual_tiles
 // ticket block of the dynamic tile walk (gemm_nt_kernel): 9 ints per stream of the handle (main | look-ahead aux), zero
 // when a launch starts -- zeroed here when first allocated, by the last workgroup of every launch from then on
 static int* dyn_tickets(oisat_ctx* h) {
-    static const bool on = !getenv("OISAT_GEMM_DYNAMIC") || atoi(getenv("OISAT_GEMM_DYNAMIC")) != 0;
-    if (!on) return nullptr;
     const bool fresh = h->ws[8] == nullptr;
     char* base = (char*)oisat_ws(h, 8, 256);
     if (!base) return nullptr;
@@ -1682,7 +1661,7 @@ int launch_gemm(oisat_ctx* h, const char* name, float* C, int64_t ldc, const flo
     }
     // too few 128x128 tiles for the 512 workgroup slots: 64x64 tiles, four workgroups per CU; the in-place TRSM form
     // (C aliases A, N == K == 128) takes 64 x 128 tiles (gemm_nt_rows64_kernel).
-    static const int small_max = getenv("OISAT_SMALL_TILES") ? atoi(getenv("OISAT_SMALL_TILES")) : 700;
+    constexpr int small_max = 700;
     if (ntiles <= small_max && h->small_tiles && C != A) {
         const int sm = (int)(M / SB), sn = (int)(N / SB);
         const int64_t st = lower ? (int64_t)sn * sm - (int64_t)sn * (sn - 1) / 2 : (int64_t)sm * sn;
@@ -1718,8 +1697,8 @@ static inline int64_t tiles_lower(int64_t ntm, int64_t ntn) { return ntn * ntm -
 // a month's 48 tiles factor in 23.6 ms instead of 25.6.  For one system or a couple of polar caps the same launches are
 // latency-bound and the extra one-workgroup step between the two diagonal blocks costs more than the saved pass
 // (10,000 observations: 8.6 ms per analysis against 8.0), so those keep single-block leaves.
-static const int kLeafPairsMin = getenv("OISAT_LEAF_PAIRS_MIN") ? atoi(getenv("OISAT_LEAF_PAIRS_MIN")) : 8;
-static const bool kSinglePairs = getenv("OISAT_LEAF_PAIRS_SINGLE") && atoi(getenv("OISAT_LEAF_PAIRS_SINGLE")) != 0;
+static const int kLeafPairsMin = 8;                     // lock-step batches of at least this many systems take leaf PAIRS (fewer: 8.6 vs 8.0 ms at 1e4 observations)
+static const bool kSinglePairs = false;                  // (single systems keep single-block leaves)
 // split point of the node [b0, b1): the left part gets ceil(half), rounded up to an even number of blocks when leaves are
 // pairs (so that the tree ends in pairs wherever it can); the one rule of potrf_rec, potrf_rec_batched and the tile tables
 static inline int64_t split_mid(int64_t b0, int64_t b1, bool pairs) {
@@ -1804,7 +1783,7 @@ int launch_gemm_batched(oisat_ctx* h, const char* name, const ChBatch& bt, Batch
         ++cnt;
     }
     if (cnt == 0) return OISAT_OK;
-    static const int small_max = getenv("OISAT_SMALL_TILES") ? atoi(getenv("OISAT_SMALL_TILES")) : 700;
+    constexpr int small_max = 700;
     // OISAT_PROF_DETAIL=1 (profiling aid): one profile record per launch shape -- "name K tiles members" -- instead of per name
     static const bool detail = getenv("OISAT_PROF_DETAIL") && atoi(getenv("OISAT_PROF_DETAIL")) != 0;
     char dname[64];
@@ -1957,20 +1936,10 @@ int potrf_lookahead(oisat_ctx* h, float* S, int64_t ld, int64_t nb, float* tinv,
         // lowest priority: the bulk updates must not sit in front of the panel chain when a CU slot frees up
         int prio_low = 0, prio_high = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
-        const char* pe = getenv("OISAT_AUX_PRIORITY");
-        const int prio = pe ? atoi(pe) : prio_low;
-        // OISAT_AUX_FREE_CUS=k: keep the first k CUs (bits of the queue's CU mask) off limits for the bulk updates, so
-        // that the panel chain's one-workgroup kernels always find a home (round 1, when the diagonal kernel needed
-        // 137 KB of LDS = a whole CU; every masked GEMM loses >= 12 %)
-        const char* fe = getenv("OISAT_AUX_FREE_CUS");
-        const int nfree = fe ? atoi(fe) : 0;
-        if (nfree > 0 && nfree < h->cu_count) {
-            std::vector<uint32_t> mask((h->cu_count + 31) / 32, 0xffffffffu);
-            for (int b = 0; b < nfree; ++b) mask[b / 32] &= ~(1u << (b % 32));
-            HIP_TRY(hipExtStreamCreateWithCUMask(&h->aux_stream, (uint32_t)mask.size(), mask.data()));
-        } else {
-            HIP_TRY(hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, prio));
-        }
+        const int prio = prio_low;
+        // (round 1 also tried keeping CUs off limits for the bulk updates -- a CU-masked stream -- so that the panel chain's
+        // one-workgroup kernels always find a home: every masked GEMM loses >= 12 %, profiles/EXPERIMENTS.md)
+        HIP_TRY(hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, prio));
     }
     while ((int64_t)h->sync_events.size() < 2 * np + 2) {
         hipEvent_t ev;
@@ -2106,9 +2075,8 @@ int trsv_solve(oisat_ctx* h, const ChFactor& f, double* rhs_pad, double* fwd, co
     char* ctl = base + 16;
     // a second LDS tile per workgroup (132 KB: one workgroup per CU) when every block row still gets its own CU at once;
     // larger systems keep two workgroups per CU in flight (they are bound by streaming L, not by the hop latency)
-    static const bool allow_two = !getenv("OISAT_TRSV_TWO_TILES") || atoi(getenv("OISAT_TRSV_TWO_TILES")) != 0;
-    static const int rows_per_wg = getenv("OISAT_TRSV_ROWS_PER_WG") && atoi(getenv("OISAT_TRSV_ROWS_PER_WG")) > 0
-                                       ? atoi(getenv("OISAT_TRSV_ROWS_PER_WG")) : 1;
+    constexpr bool allow_two = true;
+    constexpr int rows_per_wg = 1;                       // (four rows per workgroup: 0.54 vs 0.25 ms per sweep at 1e4 observations)
     const int grid = (int)cdiv(nb, rows_per_wg);
     const int two = allow_two && grid <= h->cu_count ? 1 : 0;
     const size_t shm = sizeof(float) * NB * TLD * (two ? 2 : 1);
@@ -2156,11 +2124,6 @@ hipError_t dense_kernel_attributes() {
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)trsv_batched_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)(sizeof(float) * NB * TLD));
-        if (e == hipSuccess) {
-            const char* env = getenv("OISAT_CHAIN_PRIO");
-            const int prio = env ? atoi(env) : 0;
-            if (prio >= 1 && prio <= 3) e = hipMemcpyToSymbol(HIP_SYMBOL(g_chain_prio), &prio, sizeof(int));
-        }
         return e;
     }();
     return attr_rc;

@@ -335,18 +335,16 @@ class BatchedFactor:
         every = list(order)
         # Task-graph factorization (csrc/dense_dag.inc; OISAT_DAG=0 turns it off): ONE persistent launch factors systems of
         # any mix of sizes -- tiles and polar caps together, the systems entering the launch in waves, every system's chain on
-        # a workgroup of its own, the tile tasks drawn from one list -- so a batch of up to OISAT_DAG_MAX_SYSTEMS systems
-        # (default 1024) is ONE group (OISAT_DAG_GROUP systems per launch at most).  Measured against the two lock-step groups
+        # a workgroup of its own, the tile tasks drawn from one list -- so a batch of up to 1024 systems is ONE group (larger
+        # ones keep the lock-step recursion, and so does a batch whose chains would crowd the handle's CUs: the library
+        # decides, oisat_batch_is_task_graph tells).  Measured against the two lock-step groups
         # of the recursion: a month's 50 systems 62 vs 66 ms, a rank's 75 / 150 / 300 units of config 4 0.091 / 0.177 / 0.352 vs
         # 0.103 / 0.185 / 0.357 s, all 600 units 0.700 vs 0.706 s (what the one launch gains its fully exposed solve phase
         # costs).  Several launches side by side are what must be avoided: every launch's chains are resident and its tile
         # tasks starve (seven launches of 96: 1.03 s).
-        self.dag = (os.environ.get("OISAT_DAG", "-1") != "0" and bool(order)
-                    and len(order) <= int(os.environ.get("OISAT_DAG_MAX_SYSTEMS", "1024"))
-                    and order[0].mp // NB <= int(os.environ.get("OISAT_DAG_MAX_BLOCKS", str(1 << 20))))
+        self.dag = os.environ.get("OISAT_DAG", "-1") != "0" and bool(order) and len(order) <= 1024
         if self.dag:
-            per = max(1, int(os.environ.get("OISAT_DAG_GROUP", "1024")))
-            groups = [order[i:i + per] for i in range(0, len(order), per)]
+            groups = [order]
             order = []
         cur = []
         for p in order:
@@ -356,40 +354,28 @@ class BatchedFactor:
             cur.append(p)
         if cur:
             groups.append(cur)
-        # enqueue order (OISAT_BATCH_ORDER): "largest" (default) -- the group with the longest dependent chain first: in a
-        # 720x1440 month the two polar caps (137 diagonal blocks each) are the critical path and used to sit idle for
-        # 9 ms of a 73 ms span behind the tile group's first launches (profiles/r02_e_tiled_phases.txt); "smallest" is
-        # round 2's order.  Whatever the order, a group's solves are released when THAT group is factored (run() polls).
-        # OISAT_BATCH_SOLVE=1 (default): the gain solves and increments of a group run in lock-step on the group's stream right
-        # behind its factorization (oisat_batch_solve); 0: round 2's form -- the host waits for the group and enqueues every
-        # plan's solve on its lane
-        self.batched_solve = os.environ.get("OISAT_BATCH_SOLVE", "1") != "0" and all(p.work is not None for p in every)
+        # the lock-step recursion (OISAT_DAG=0, or more than 1024 systems) enqueues the group with the longest dependent chain
+        # first: in a 720x1440 month the two polar caps (137 diagonal blocks each) are the critical path.  Whatever the order, a
+        # group's solves are released when THAT group is factored.  The gain solves and increments of a group run in lock-step on
+        # the group's stream right behind its factorization (oisat_batch_solve) when every plan owns its work vectors
+        self.batched_solve = all(p.work is not None for p in every)
         # ... or, with the task graph, as tasks of the factorization's own launch (oisat_batch_analyse, OISAT_DAG_SOLVE=1): the
         # same bits in one launch instead of ~15.  Not the default: it ties for one month (61.5-63 vs 62.6 ms) and loses for
         # twelve (0.73 vs 0.71 s) -- the launch is bound by workgroup-slot time, and fp64 VALU work does not overlap with the
         # MFMA K-loop on this chip (csrc/dense_dag.inc "WHAT IT BOUGHT").  The tests run both and compare them bit for bit.
         self.one_launch = self.dag and self.batched_solve and os.environ.get("OISAT_DAG_SOLVE", "0") == "1"
-        self.order = os.environ.get("OISAT_BATCH_ORDER", "largest")
-        self.groups = groups if self.order == "largest" else groups[::-1]
+        self.groups = groups
         # schedule (OISAT_BATCH_SCHEDULE): "overlap" (default) -- one stream per group, all groups side by side;
         # "sequential" -- the groups one after the other (each one's dependent chain then runs at its isolated speed and
-        # its solves go underneath the next group's factorization).
+        # its solves go underneath the next group's factorization).  Same fields either way (tested).
         self.schedule = os.environ.get("OISAT_BATCH_SCHEDULE", "overlap")
-        # OISAT_BATCH_RESERVE_CUS=r: the groups other than the one with the longest chain run on streams that keep off r CUs
-        # of every XCD, which the critical group's chain kernels then find free of GEMM waves
-        reserve = int(os.environ.get("OISAT_BATCH_RESERVE_CUS", "0")) if len(groups) > 1 else 0
-        major0 = max(range(len(self.groups)), key=lambda gi: self.groups[gi][0].mp) if self.groups else 0
-        self.ctxs = [(_hip.Context(device).own_stream() if gi == major0 or reserve == 0
-                      else _hip.Context(device).own_stream_masked(reserve)) for gi in range(len(self.groups))]
+        self.ctxs = [_hip.Context(device).own_stream() for _ in self.groups]
         # sharing (oisat_set_share): the group with the longest chain is the critical path of the whole batch -- its waves
-        # get priority on the SIMDs they share with the other groups' GEMMs, and the other groups' persistent GEMM launches
-        # leave one workgroup slot per CU free (OISAT_BATCH_MAJOR_PRIO 0..3, OISAT_BATCH_MINOR_WG 1 | 2)
+        # get priority on the SIMDs they share with the other groups' GEMMs (measured: profiles/EXPERIMENTS.md, round 3)
         if len(self.groups) > 1:
             major = max(range(len(self.groups)), key=lambda gi: self.groups[gi][0].mp)
-            mprio = int(os.environ.get("OISAT_BATCH_MAJOR_PRIO", "3"))
-            mwg = int(os.environ.get("OISAT_BATCH_MINOR_WG", "2"))
             for gi, ctx in enumerate(self.ctxs):
-                ctx.check(ctx.lib.oisat_set_share(ctx.h, mprio if gi == major else 0, 2 if gi == major else mwg))
+                ctx.check(ctx.lib.oisat_set_share(ctx.h, 3 if gi == major else 0, 2))
         self.ids = []
         for g, ctx in zip(self.groups, self.ctxs):
             n = len(g)
@@ -582,7 +568,7 @@ class LanePool:
         ~10 us per launch -- is slower than the GPU (91 ms of launching for 30 ms of work at 720x1440 / 1e5 obs);
         ctypes releases the GIL inside the library calls, and each handle is driven by exactly one thread."""
         work = [(li, fns) for li, fns in enumerate(per_lane) if fns]
-        if len(work) <= 1 or os.environ.get("OISAT_ENQUEUE_THREADS", "1") == "0":
+        if len(work) <= 1:
             for _, fns in work:
                 for fn in fns:
                     fn()

@@ -25,6 +25,8 @@ a singular neighbourhood raises ``LinAlgError`` only when it feeds an unmasked t
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from . import _hip
@@ -366,17 +368,36 @@ def _upscaler(X: np.ndarray, Y: np.ndarray, Z: np.ndarray, ctm_models_coordinate
     return plan.ctm_longitude, plan.ctm_latitude, Zc, False
 
 
+_NOT_GIVEN = object()
+
+
+def _triangulate(lon, lat):
+    """``Delaunay(points)`` of a granule's pixel centres as the reference builds it (interpolator.py:151-155), or None when
+    qhull cannot.  Host only (no device call): ``interpolator_many`` runs it on worker threads -- qhull releases the GIL."""
+    from scipy.spatial import Delaunay
+    pts = np.column_stack((np.ravel(lon), np.ravel(lat))).astype(np.float64)
+    try:
+        return Delaunay(pts)
+    except Exception:
+        return None
+
+
 # --------------------------------------------------------------------------------------------
 class _GranuleRegridder:
     """Everything ``interpolator()`` needs for one granule, resident in HBM."""
 
-    def __init__(self, sat_data, grid_size, ctm_models_coordinate, flag_thresh, interpolator_type=4):
+    def __init__(self, sat_data, grid_size, ctm_models_coordinate, flag_thresh, interpolator_type=4, triangulation=_NOT_GIVEN):
+        """``triangulation``: the granule's ``scipy.spatial.Delaunay`` built ahead of time (``interpolator_many``), or None
+        if qhull failed on it; by default it is built here."""
         self.ctx = ctx = _hip.context()
         self.kind = int(interpolator_type)
         self.tri = None
         self.ok = True
         if self.kind == 1:
-            self.tri = TriIndex.from_points(sat_data.longitude_center, sat_data.latitude_center)
+            if triangulation is _NOT_GIVEN:
+                self.tri = TriIndex.from_points(sat_data.longitude_center, sat_data.latitude_center)
+            else:
+                self.tri = TriIndex(triangulation) if triangulation is not None else None
             if self.tri is None:            # qhull failed: the reference skips the granule (interpolator.py:151-155)
                 self.ok = False
                 return
@@ -457,6 +478,48 @@ class _GranuleRegridder:
         return X, Y, [Z[f] for f in range(nf)], need
 
 
+def interpolator_many(interpolator_type: int, grid_size: float, granules, ctm_models_coordinate: dict, flag_thresh=0.75, workers=None):
+    """``[interpolator(type, grid_size, g, ctm, flag_thresh) for g in granules]`` -- the loop the reference's readers run over
+    a month's files (reader.py:1405, one joblib task per file; interpolator.py:151-159 builds the triangulation inside each)
+    -- with the HOST part of type 1 taken off the critical path: the Delaunay triangulations of the granules ahead (qhull:
+    0.5 s of a 0.6 s call for a 98,640-pixel OMI granule, against 0.1 s of device work and copies) are built by ``workers``
+    host threads (default: the CPUs this process may use, at most 8) while the device regrids the current granule.  qhull
+    runs without the GIL (measured: 8 threads, 0.11 s per granule on 8 cores).  Same triangulations, same order of
+    evaluation: the outputs are those of the serial calls bit for bit (``None`` entries and ``None`` results as there).
+    Only the main thread touches the device handle."""
+    granules = list(granules)
+    if interpolator_type != 1 or len(granules) < 2:
+        return [None if g is None else interpolator(interpolator_type, grid_size, g, ctm_models_coordinate, flag_thresh) for g in granules]
+    from concurrent.futures import ThreadPoolExecutor
+    if workers is None:
+        try:
+            ncpu = len(os.sched_getaffinity(0))
+        except AttributeError:
+            ncpu = os.cpu_count() or 1
+        workers = max(1, min(8, ncpu))
+    ahead = 2 * int(workers)                              # triangulations in flight / waiting: bounded (each holds ~10 MB)
+    out = []
+    with ThreadPoolExecutor(max_workers=int(workers), thread_name_prefix="oisat-qhull") as pool:
+        futures = {}
+
+        def submit(k):
+            g = granules[k]
+            if g is not None:
+                futures[k] = pool.submit(_triangulate, g.longitude_center, g.latitude_center)
+
+        for k in range(min(ahead, len(granules))):
+            submit(k)
+        for k, g in enumerate(granules):
+            if k + ahead < len(granules):
+                submit(k + ahead)
+            if g is None:
+                out.append(None)
+                continue
+            tri = futures.pop(k).result()
+            out.append(_interpolate_granule(interpolator_type, grid_size, g, ctm_models_coordinate, flag_thresh, tri))
+    return out
+
+
 def interpolator(interpolator_type: int, grid_size: float, sat_data, ctm_models_coordinate: dict, flag_thresh=0.75):
     '''
         The interpolator function (interpolator.py:100-291)
@@ -471,9 +534,13 @@ def interpolator(interpolator_type: int, grid_size: float, sat_data, ctm_models_
             ctm_models_coordinate [dic]: a dictionary containing lat and lon of the model
             flag_thresh [float]: the quality flag threshold
     '''
+    return _interpolate_granule(interpolator_type, grid_size, sat_data, ctm_models_coordinate, flag_thresh, _NOT_GIVEN)
+
+
+def _interpolate_granule(interpolator_type, grid_size, sat_data, ctm_models_coordinate, flag_thresh, triangulation):
     if interpolator_type not in (1, 2, 3, 4):
         raise Exception("other type of interpolation methods has not been implemented yet")
-    rg = _GranuleRegridder(sat_data, grid_size, ctm_models_coordinate, flag_thresh, interpolator_type)
+    rg = _GranuleRegridder(sat_data, grid_size, ctm_models_coordinate, flag_thresh, interpolator_type, triangulation)
     if not rg.ok:
         return None
     is_amf = isinstance(sat_data, satellite_amf)

@@ -404,3 +404,39 @@ def test_one_launch_analysis_equals_factorization_then_lock_step_solve(ctx, monk
         np.testing.assert_array_equal(a, b)
     np.testing.assert_array_equal(inc1, inc0)
     np.testing.assert_array_equal(xa1, xa0)
+
+
+# ------------------------------------------------------------------------------------------------
+# the host triangulations of type 1 off the critical path
+# ------------------------------------------------------------------------------------------------
+def test_interpolator_many_equals_the_serial_calls_bit_for_bit(ctx, capsys):
+    """interpolator_many (triangulations of the granules ahead built by host threads while the device regrids the current
+    one; reference loop: reader.py:1405, interpolator.py:151-159) against one interpolator() call per granule: every field of
+    every record the same bits, ``None`` entries kept, a granule qhull cannot triangulate (collinear pixels) skipped as the
+    reference skips it, a granule outside the model region skipped; types 4 and 2 simply loop."""
+    import dataclasses
+    from oisatgmi.interpolator import interpolator, interpolator_many
+    ctm = syn.regional_ctm_grid(-30.0, 40.0, -20.0, 60.0, 1.0, 1.25)
+    granules = [syn.swath_granule(8800 + k, nscan=150, npix=40, lat0=-25.0 + 3 * k, lat1=20.0 + 3 * k, lon_c=5.0 + 6 * k, width_deg=14.0) for k in range(6)]
+    flat = syn.swath_granule(8899, nscan=40, npix=30)
+    flat.latitude_center = np.zeros_like(flat.latitude_center)        # every pixel on one line: qhull raises, the reference returns None
+    far = syn.swath_granule(8898, nscan=60, npix=30, lat0=60.0, lat1=80.0, lon_c=150.0, width_deg=10.0)     # outside the model grid
+    batch = granules[:3] + [None, flat] + granules[3:] + [far]
+    for kind in (1, 4):
+        many = interpolator_many(kind, 0.5, batch, ctm, 0.75, workers=3)
+        assert len(many) == len(batch)
+        for g, got in zip(batch, many):
+            want = None if g is None else interpolator(kind, 0.5, g, ctm, 0.75)
+            assert (got is None) == (want is None)
+            if want is None:
+                continue
+            for f in dataclasses.fields(want):
+                a, b = getattr(want, f.name), getattr(got, f.name)
+                if isinstance(a, np.ndarray):
+                    np.testing.assert_array_equal(a, b, err_msg=f.name)
+                else:
+                    assert a == b or (a is b), f.name
+        assert many[3] is None and many[-1] is None
+        if kind == 1:
+            assert many[4] is None
+    capsys.readouterr()

@@ -122,8 +122,8 @@ threads = [threading.Thread(target=worker, args=("A m=2500", 2500, 11, True)),
            threading.Thread(target=worker, args=("C m=900", 900, 13, True)),
            threading.Thread(target=noise)]
 if os.environ.get("BATCHES", "1") != "0":
-    threads += [threading.Thread(target=batch_worker, args=("batch waves of 3", [2100, 1500, 1290, 1000, 777, 640, 300, 257, 129, 128, 100], 900, {"OISAT_DAG_WAVE": "3"})),
-                threading.Thread(target=batch_worker, args=("batch with chain servers", [1800, 900, 800, 700, 600, 500, 400, 300], 950, {"OISAT_DAG_SERVE": "3", "OISAT_DAG_WAVE": "6"}))]
+    threads += [threading.Thread(target=batch_worker, args=("batch of eleven", [2100, 1500, 1290, 1000, 777, 640, 300, 257, 129, 128, 100], 900, {})),
+                threading.Thread(target=batch_worker, args=("batch of eight", [1800, 900, 800, 700, 600, 500, 400, 300], 950, {}))]
 for t in threads:
     t.start()
 time.sleep(budget)
