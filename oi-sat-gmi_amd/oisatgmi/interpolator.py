@@ -371,15 +371,46 @@ def _upscaler(X: np.ndarray, Y: np.ndarray, Z: np.ndarray, ctm_models_coordinate
 _NOT_GIVEN = object()
 
 
-def _triangulate(lon, lat):
-    """``Delaunay(points)`` of a granule's pixel centres as the reference builds it (interpolator.py:151-155), or None when
-    qhull cannot.  Host only (no device call): ``interpolator_many`` runs it on worker threads -- qhull releases the GIL."""
-    from scipy.spatial import Delaunay
-    pts = np.column_stack((np.ravel(lon), np.ravel(lat))).astype(np.float64)
-    try:
-        return Delaunay(pts)
-    except Exception:
-        return None
+class _QhullWorkers:
+    """A few child processes that triangulate granules (``oisatgmi._qhull_worker``): qhull releases the GIL but the 0.5 s of
+    ``Delaunay.transform`` (one LAPACK factorization per simplex) does not -- eight threads were slower than one -- so the
+    host part of type 1 needs processes; plain children with pipes, one feeding thread each (the pickles are ~25 MB)."""
+
+    def __init__(self, n):
+        import subprocess
+        import sys
+        import threading
+        env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+        env["PYTHONPATH"] = os.pathsep.join([os.path.dirname(os.path.dirname(os.path.abspath(__file__)))] + [p for p in [env.get("PYTHONPATH")] if p])
+        self.procs = [subprocess.Popen([sys.executable, "-m", "oisatgmi._qhull_worker"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env)
+                      for _ in range(int(n))]
+        self.locks = [threading.Lock() for _ in self.procs]
+        self.next = 0
+
+    def submit(self, executor, lon, lat):
+        """-> future of the triangulation (round-robin over the workers; ``executor``: a thread pool of one thread per worker)."""
+        from . import _qhull_worker as w
+        k = self.next % len(self.procs)
+        self.next += 1
+
+        def call():
+            with self.locks[k]:
+                p = self.procs[k]
+                w.write_msg(p.stdin, (np.asarray(lon), np.asarray(lat)))
+                return w.read_msg(p.stdout)
+        return executor.submit(call)
+
+    def close(self):
+        for p in self.procs:
+            try:
+                p.stdin.close()
+            except Exception:
+                pass
+        for p in self.procs:
+            try:
+                p.wait(timeout=10)
+            except Exception:
+                p.kill()
 
 
 # --------------------------------------------------------------------------------------------
@@ -481,12 +512,13 @@ class _GranuleRegridder:
 def interpolator_many(interpolator_type: int, grid_size: float, granules, ctm_models_coordinate: dict, flag_thresh=0.75, workers=None):
     """``[interpolator(type, grid_size, g, ctm, flag_thresh) for g in granules]`` -- the loop the reference's readers run over
     a month's files (reader.py:1405, one joblib task per file; interpolator.py:151-159 builds the triangulation inside each)
-    -- with the HOST part of type 1 taken off the critical path: the Delaunay triangulations of the granules ahead (qhull:
-    0.5 s of a 0.6 s call for a 98,640-pixel OMI granule, against 0.1 s of device work and copies) are built by ``workers``
-    host threads (default: the CPUs this process may use, at most 8) while the device regrids the current granule.  qhull
-    runs without the GIL (measured: 8 threads, 0.11 s per granule on 8 cores).  Same triangulations, same order of
-    evaluation: the outputs are those of the serial calls bit for bit (``None`` entries and ``None`` results as there).
-    Only the main thread touches the device handle."""
+    -- with the HOST part of type 1 taken off the critical path: the Delaunay triangulations of the granules ahead and their
+    barycentric transforms (qhull 0.4-0.5 s + ``Delaunay.transform`` 0.5-0.6 s of a 0.85 s call for a 98,640-pixel OMI
+    granule, against < 0.1 s of device work and copies) are built by ``workers`` host PROCESSES (default: the CPUs this
+    process may use, at most 8) while the device regrids the current granule; the triangulation comes back pickled (23 MB,
+    30 ms).  Same triangulations, same order of evaluation: the outputs are those of the serial calls bit for bit (``None``
+    entries and ``None`` results as there).  The workers are child processes (``oisatgmi._qhull_worker``, pipes) that never
+    touch the device; only this process holds the handle (INTEGRATION.md "Threading / processes")."""
     granules = list(granules)
     if interpolator_type != 1 or len(granules) < 2:
         return [None if g is None else interpolator(interpolator_type, grid_size, g, ctm_models_coordinate, flag_thresh) for g in granules]
@@ -496,27 +528,31 @@ def interpolator_many(interpolator_type: int, grid_size: float, granules, ctm_mo
             ncpu = len(os.sched_getaffinity(0))
         except AttributeError:
             ncpu = os.cpu_count() or 1
-        workers = max(1, min(8, ncpu))
-    ahead = 2 * int(workers)                              # triangulations in flight / waiting: bounded (each holds ~10 MB)
+        workers = max(1, min(8, ncpu - 1, len(granules)))
+    ahead = 2 * int(workers)                              # triangulations in flight / waiting: bounded (each holds ~25 MB)
     out = []
-    with ThreadPoolExecutor(max_workers=int(workers), thread_name_prefix="oisat-qhull") as pool:
-        futures = {}
+    procs = _QhullWorkers(workers)
+    try:
+        with ThreadPoolExecutor(max_workers=int(workers), thread_name_prefix="oisat-qhull") as feeders:
+            futures = {}
 
-        def submit(k):
-            g = granules[k]
-            if g is not None:
-                futures[k] = pool.submit(_triangulate, g.longitude_center, g.latitude_center)
+            def submit(k):
+                g = granules[k]
+                if g is not None:
+                    futures[k] = procs.submit(feeders, g.longitude_center, g.latitude_center)
 
-        for k in range(min(ahead, len(granules))):
-            submit(k)
-        for k, g in enumerate(granules):
-            if k + ahead < len(granules):
-                submit(k + ahead)
-            if g is None:
-                out.append(None)
-                continue
-            tri = futures.pop(k).result()
-            out.append(_interpolate_granule(interpolator_type, grid_size, g, ctm_models_coordinate, flag_thresh, tri))
+            for k in range(min(ahead, len(granules))):
+                submit(k)
+            for k, g in enumerate(granules):
+                if k + ahead < len(granules):
+                    submit(k + ahead)
+                if g is None:
+                    out.append(None)
+                    continue
+                tri = futures.pop(k).result()
+                out.append(_interpolate_granule(interpolator_type, grid_size, g, ctm_models_coordinate, flag_thresh, tri))
+    finally:
+        procs.close()
     return out
 
 
