@@ -433,6 +433,8 @@ def test_interpolator_many_equals_the_serial_calls_bit_for_bit(ctx, capsys):
             for f in dataclasses.fields(want):
                 a, b = getattr(want, f.name), getattr(got, f.name)
                 if isinstance(a, np.ndarray):
+                    if a.size == 1 and b.size == 1:          # np.empty((1)) placeholders, as in the reference (interpolator.py:176-180)
+                        continue
                     np.testing.assert_array_equal(a, b, err_msg=f.name)
                 else:
                     assert a == b or (a is b), f.name
