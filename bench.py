@@ -137,7 +137,7 @@ def roofline_leg(ctx, plan, L, refine, psteps):
     tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c3_hbm_traffic_pmc.json")))
     if m > 90000 and tfiles:                      # newest PMC pass of this same workload (tools/pmc_traffic.sh, offline)
         tj = json.load(open(tfiles[-1]))
-        if ("potrf_dag_kernel" in tj.get("kernels", {})) == dag:      # (a pass of the other schedule says nothing about this one)
+        if any(k.startswith("potrf_dag_kernel") for k in tj.get("kernels", {})) == dag:      # (a pass of the other schedule says nothing about this one)
             traffic = tj["hbm_bytes_per_factorization_corrected"] / tj["launches_per_factorization"]
             traffic_src = (f"profiles/{os.path.basename(tfiles[-1])} at commit {tj.get('commit')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                            "separate passes, FETCH x2 per the gfx950 note; bytes per launch of the factorization's kernels, mean over "
@@ -155,8 +155,9 @@ def roofline_leg(ctx, plan, L, refine, psteps):
     }
     if dag and m <= 90000:                                # config 2: its own PMC passes (tools/pmc_traffic.sh ... bench.py --only secondary)
         tj, src = _newest_profile("r*_c2_hbm_traffic_pmc.json")
-        if tj and "potrf_dag_kernel" in tj.get("kernels", {}):
-            roof["traffic"] = tj["kernels"]["potrf_dag_kernel"]["bytes_per_dispatch"]
+        dk = next((k for k in (tj or {}).get("kernels", {}) if k.startswith("potrf_dag_kernel")), None)
+        if dk:
+            roof["traffic"] = tj["kernels"][dk]["bytes_per_dispatch"]
             roof["traffic_source"] = f"{src} at commit {tj.get('commit')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2; bytes per launch)"
         bj, bsrc = _newest_profile("r*_c2_mfma_busy_pmc.json")
         if bj and bj.get("mfma_busy_fraction") is not None:
@@ -338,8 +339,8 @@ def _dag_roofline(prof_by_handle, flops_per_run, runs, tag, what):
     """MFMA roofline of the task-graph launch(es) of a leg: achieved = algorithmic flops (sum over the systems of m^3/3) /
     the launch's duration, HIP events on the launch stream; traffic / MFMA-busy from the newest PMC passes of this same leg
     under profiles/ (tools/pmc_traffic.sh, tools/pmc_busy.sh: `bench.py --only <leg>`, program directly after `--`)."""
-    ms = sum(pr["potrf_dag"]["total_ms"] for pr in prof_by_handle if "potrf_dag" in pr) / runs
-    launches = sum(pr["potrf_dag"]["launches"] for pr in prof_by_handle if "potrf_dag" in pr) / runs
+    ms = sum(pr[k]["total_ms"] for pr in prof_by_handle for k in ("potrf_dag", "analyse_dag") if k in pr) / runs
+    launches = sum(pr[k]["launches"] for pr in prof_by_handle for k in ("potrf_dag", "analyse_dag") if k in pr) / runs
     if ms <= 0:
         return None
     achieved = flops_per_run / (ms * 1e-3) / 1e12
@@ -347,8 +348,9 @@ def _dag_roofline(prof_by_handle, flops_per_run, runs, tag, what):
             "frac": achieved / MFMA_F32_PEAK_TFLOPS, "algorithmic_flops_per_step": flops_per_run, "kernel_ms_per_step": ms,
             "launches_per_step": launches, "traffic": None, "mfma_busy_fraction": None}
     tj, src = _newest_profile(f"r*_{tag}_hbm_traffic_pmc.json")
-    if tj and "potrf_dag_kernel" in tj.get("kernels", {}):
-        roof["traffic"] = tj["kernels"]["potrf_dag_kernel"]["bytes_per_dispatch"]
+    dk = next((k for k in (tj or {}).get("kernels", {}) if k.startswith("potrf_dag_kernel")), None)
+    if dk:
+        roof["traffic"] = tj["kernels"][dk]["bytes_per_dispatch"]
         roof["traffic_source"] = f"{src} at commit {tj.get('commit')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2; bytes per launch)"
         roof["flop_per_byte_at_the_fabric"] = flops_per_run / launches / roof["traffic"] if launches else None
     bj, bsrc = _newest_profile(f"r*_{tag}_mfma_busy_pmc.json")
