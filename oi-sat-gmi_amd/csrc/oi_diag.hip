@@ -1,7 +1,7 @@
 // Element-wise optimal interpolation: optimal_interpolation.py:6-52 of the reference.
 //
 //   sweep   (:26-33)  for each of the 99 scalings s: t = Sa*s, K = t*(t+So)^-1, Sb = (1-K)*t,
-//                     AK = 1 - Sb/t, mean_s = nanmean(AK)
+//                     AK = 1 - Sb/t, mean_s = nanmean(AK)      (the means: AK = K where t != 0, see ak_of)
 //   apply   (:14,:46-52) Y[Y<0]=0; inc = K*(Y-Xa); Xb = Xa+inc; err = sqrt(Sb) for the chosen s
 //
 // HBM layout: four (ny*nx) fields of T in, four out, all contiguous; nothing else.
@@ -20,12 +20,17 @@ constexpr int kCurveBlocks = 1024;      // fixed: part of the reproducibility co
 constexpr int kCurveThreads = 256;
 constexpr int kCurveWaves = kCurveBlocks * kCurveThreads / kWave;
 
+// AK of the sweep (optimal_interpolation.py:27-31): K = t (t + So)^-1, Sb = (1 - K) t, AK = 1 - Sb / t.  For the 99 MEANS the
+// last two steps are taken algebraically: Sb / t = 1 - K exactly in real arithmetic, so AK = K wherever t != 0, and 0/0 = NaN
+// (dropped by nanmean) where t = 0 -- within one rounding of the reference's value (1.1e-16 absolute in float64, nine orders
+// inside the curve's 1e-12 parity bar and four inside the smallest knee margin seen, 1.9e-6), for one division per (cell,
+// scaling) instead of two: the sweep is bound by exactly those divisions.  The analysis kernel (oi_apply_kernel) keeps the
+// reference's order: its AK FIELD is a returned quantity.
 template <typename T>
 __device__ __forceinline__ T ak_of(T sa, T so, T s) {
     T t = sa * s;
     T k = t * (T(1) / (t + so));
-    T sb = (T(1) - k) * t;
-    return T(1) - sb / t;
+    return t == T(0) ? nan_of<T>() : k;
 }
 
 template <typename T>
