@@ -249,13 +249,25 @@ int oisat_linear_interp_forced(oisat_ctx* h, int dtype, const double* tlon, cons
  * interpolator.py:21-27): thin-plate-spline kernel, degree-1 polynomial tail, no smoothing; per target the
  * `neighbors` (3..5, = min(5, P) in scipy) nearest points, ids sorted ascending, one (neighbors+3)^2 system
  * solved in double.  nn_idx: nearest point per target from oisat_nn_query with max_dist = cell (the mask
- * radius 2*threshold); targets with nn_idx < 0 are NaN after the reference's mask and are skipped.  A NaN
- * value makes every target whose neighbourhood holds it NaN (as dgesv does).  *n_singular (host, may be
- * NULL) = number of targets whose system had a zero pivot (scipy raises LinAlgError("Singular matrix"));
- * those targets are written NaN.  Synchronises internally. */
+ * radius 2*threshold); targets with nn_idx < 0 are NaN after the reference's mask and get no value here
+ * (oisat_rbf_check_masked looks at their neighbourhoods).  A NaN value makes every target whose
+ * neighbourhood holds it NaN (as dgesv does).  *n_singular (host, may be NULL) = number of evaluated
+ * targets whose system had a zero pivot (scipy raises LinAlgError("Singular matrix")); those targets are
+ * written NaN.  Synchronises internally. */
 int oisat_rbf_interp(oisat_ctx* h, int dtype, const double* plon, const double* plat, int64_t P,
                      const double* tlon, const double* tlat, int64_t T, const int32_t* nn_idx, double cell,
                      int neighbors, const void* values, int nfields, void* out, int64_t* n_singular);
+
+/* The other half of interpolator.py:21-27: scipy evaluates RBFInterpolator at EVERY target and masks afterwards,
+ * so a singular neighbourhood raises LinAlgError for the whole call even when its target is masked (a regular
+ * lattice of points and a target beyond its edge: five collinear neighbours).  For the targets with nn_idx < 0:
+ * the `neighbors` nearest points are found (two-level search on a hash of at most 128 x 128 cells, so that a
+ * target a whole domain away from every point costs no more than a near one), the system is factored, and
+ * *n_singular (host) = number of zero pivots met.  Independent of the values: once per (points, targets) pair.
+ * Synchronises internally. */
+int oisat_rbf_check_masked(oisat_ctx* h, const double* plon, const double* plat, int64_t P, const double* tlon,
+                           const double* tlat, int64_t T, const int32_t* nn_idx, double cell, int neighbors,
+                           int64_t* n_singular);
 
 /* _upscaler fused (interpolator.py:72-91): box-average of the ky*kx window around fine node
  * idx[t] (symmetric boundary, NaN-poisoning, optional variance kernel), evaluated only at the

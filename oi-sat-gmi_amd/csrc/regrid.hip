@@ -487,74 +487,62 @@ __global__ __launch_bounds__(256) void linear_interp_kernel(const double* __rest
 // registers, solves for the evaluation weights w = A^-1 vec (A is symmetric, so out = w[:K] . d) and
 // applies them to every stacked field.  A NaN value poisons its neighbourhood exactly as a NaN
 // right-hand side poisons dgesv's coefficients.  A zero pivot is LAPACK's info > 0: counted, NaN written.
-// Targets whose nearest point is beyond the mask radius (nn_idx < 0) are skipped: NaN after the mask anyway.
+// Targets whose nearest point is beyond the mask radius (nn_idx < 0) come back NaN after the mask anyway, but scipy evaluates
+// them too and one singular neighbourhood among them raises LinAlgError for the whole call (a regular lattice of points and
+// a target beyond its edge: five collinear neighbours).  They get a second launch (FAR) on a coarse hash (at most 128 cells
+// a side, so an isolated target's ring search is bounded) that finds the neighbours, factors and counts zero pivots, and
+// writes nothing.
 __device__ __forceinline__ double tps(double r2) {      // r^2 log r with r = sqrt(r2), evaluated as scipy does
     const double r = sqrt(r2);
     return r == 0.0 ? 0.0 : (r * r) * log(r);
 }
 
-template <typename T, int K>
-__global__ __launch_bounds__(64) void rbf_interp_kernel(const double* __restrict__ px, const double* __restrict__ py,
-                                                         const double* __restrict__ tx, const double* __restrict__ ty, int64_t Tn,
-                                                         const int32_t* __restrict__ nn_idx, HashGrid g,
-                                                         const unsigned* __restrict__ start, const int32_t* __restrict__ sorted,
-                                                         const T* __restrict__ values, int64_t P, int nfields, T* __restrict__ out,
-                                                         int* __restrict__ n_singular) {
-    constexpr int N = K + 3;
-    const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (t >= Tn) return;
-    bool ok = nn_idx[t] >= 0;
-    const double x = tx[t], y = ty[t];
-    ok = ok && x == x && y == y;
-    double bd[K];
-    int32_t id[K];
+// One hash cell into the K best (distance, then index) of a target.  A cell wholly farther than the K-th candidate holds
+// nothing new (bounds widened by 1e-9 of a cell against the rounding of the cell assignment; the box's edge cells also hold
+// what was clamped into them).
+template <int K>
+__device__ __forceinline__ void knn_scan_cell(const HashGrid& g, double hcell, int xx, int yy, double x, double y,
+                                              const double* __restrict__ px, const double* __restrict__ py,
+                                              const unsigned* __restrict__ start, const int32_t* __restrict__ sorted,
+                                              double (&bd)[K], int32_t (&id)[K]) {
+    const int c = yy * g.nbx + xx;
+    const unsigned s0 = start[c], s1 = start[c + 1];
+    if (s0 == s1) return;
+    const double xlo = xx == 0 ? -__builtin_inf() : g.x0 + (xx - 1e-9) * hcell;
+    const double xhi = xx == g.nbx - 1 ? __builtin_inf() : g.x0 + (xx + 1 + 1e-9) * hcell;
+    const double ylo = yy == 0 ? -__builtin_inf() : g.y0 + (yy - 1e-9) * hcell;
+    const double yhi = yy == g.nby - 1 ? __builtin_inf() : g.y0 + (yy + 1 + 1e-9) * hcell;
+    const double gx = fmax(0.0, fmax(xlo - x, x - xhi)), gy = fmax(0.0, fmax(ylo - y, y - yhi));
+    if ((gx * gx + gy * gy) * (1.0 - 1e-12) > bd[K - 1]) return;
+    for (unsigned s = s0; s < s1; ++s) {
+        const int32_t i = sorted[s];
+        const double dx = px[i] - x, dy = py[i] - y;
+        const double d2 = dx * dx + dy * dy;
+        if (d2 < bd[K - 1] || (d2 == bd[K - 1] && i < id[K - 1])) {
+            bd[K - 1] = d2;
+            id[K - 1] = i;
 #pragma unroll
-    for (int q = 0; q < K; ++q) { bd[q] = __builtin_inf(); id[q] = -1; }
-    if (ok) {
-        int cx, cy;
-        cell_of(g, x, y, cx, cy);
-        const double hcell = 1.0 / g.inv_h;
-        int rlast = cx > cy ? cx : cy;                       // ring beyond which every cell has been visited
-        if (g.nbx - 1 - cx > rlast) rlast = g.nbx - 1 - cx;
-        if (g.nby - 1 - cy > rlast) rlast = g.nby - 1 - cy;
-        for (int r = 0; r <= rlast; ++r) {
-            for (int yy = cy - r; yy <= cy + r; ++yy) {
-                if (yy < 0 || yy >= g.nby) continue;
-                const bool edge_row = (yy == cy - r) || (yy == cy + r);
-                const int step = edge_row ? 1 : (2 * r > 0 ? 2 * r : 1);      // interior rows: only the two end cells
-                for (int xx = cx - r; xx <= cx + r; xx += step) {
-                    if (xx < 0 || xx >= g.nbx) continue;
-                    const int c = yy * g.nbx + xx;
-                    for (unsigned s = start[c]; s < start[c + 1]; ++s) {
-                        const int32_t i = sorted[s];
-                        const double dx = px[i] - x, dy = py[i] - y;
-                        const double d2 = dx * dx + dy * dy;
-                        if (d2 < bd[K - 1] || (d2 == bd[K - 1] && i < id[K - 1])) {
-                            bd[K - 1] = d2;
-                            id[K - 1] = i;
-#pragma unroll
-                            for (int q = K - 1; q > 0; --q) {
-                                const bool sw = bd[q] < bd[q - 1] || (bd[q] == bd[q - 1] && id[q] < id[q - 1]);
-                                const double td = bd[q];
-                                const int32_t ti = id[q];
-                                bd[q] = sw ? bd[q - 1] : td;
-                                id[q] = sw ? id[q - 1] : ti;
-                                bd[q - 1] = sw ? td : bd[q - 1];
-                                id[q - 1] = sw ? ti : id[q - 1];
-                            }
-                        }
-                    }
-                }
+            for (int q = K - 1; q > 0; --q) {
+                const bool sw = bd[q] < bd[q - 1] || (bd[q] == bd[q - 1] && id[q] < id[q - 1]);
+                const double td = bd[q];
+                const int32_t ti = id[q];
+                bd[q] = sw ? bd[q - 1] : td;
+                id[q] = sw ? id[q - 1] : ti;
+                bd[q - 1] = sw ? td : bd[q - 1];
+                id[q - 1] = sw ? ti : id[q - 1];
             }
-            // every unvisited point lies at least r cells away along one axis
-            const double reach = r * hcell * (1.0 - 1e-12);
-            if (id[K - 1] >= 0 && bd[K - 1] < reach * reach) break;
         }
-        ok = id[K - 1] >= 0;
     }
+}
+
+// The (K+3)x(K+3) system of one target on its K neighbours: ids sorted, built, factored, evaluation weights solved for.
+// Returns true when a pivot was exactly zero (LAPACK's info > 0).
+template <int K>
+__device__ __forceinline__ bool rbf_factor(double x, double y, int32_t (&id)[K], const double* __restrict__ px,
+                                           const double* __restrict__ py, double (&w)[K + 3]) {
+    constexpr int N = K + 3;
     bool singular = false;
-    double w[N];
-    if (ok) {
+    {
 #pragma unroll
         for (int a = 0; a < K - 1; ++a)                       // ids ascending (np.sort(yindices, axis=1))
 #pragma unroll
@@ -637,6 +625,58 @@ __global__ __launch_bounds__(64) void rbf_interp_kernel(const double* __restrict
             for (int j = i + 1; j < N; ++j) sacc -= a[i][j] * w[j];
             w[i] = sacc / a[i][i];
         }
+    }
+    return singular;
+}
+
+template <typename T, int K>
+__global__ __launch_bounds__(64) void rbf_interp_kernel(const double* __restrict__ px, const double* __restrict__ py,
+                                                         const double* __restrict__ tx, const double* __restrict__ ty, int64_t Tn,
+                                                         const int32_t* __restrict__ nn_idx, HashGrid g,
+                                                         const unsigned* __restrict__ start, const int32_t* __restrict__ sorted,
+                                                         const T* __restrict__ values, int64_t P, int nfields, T* __restrict__ out,
+                                                         int* __restrict__ n_singular) {
+    constexpr int N = K + 3;
+    const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (t >= Tn) return;
+    bool ok = nn_idx[t] >= 0;
+    const double x = tx[t], y = ty[t];
+    ok = ok && x == x && y == y;
+    double bd[K];
+    int32_t id[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) { bd[q] = __builtin_inf(); id[q] = -1; }
+    if (ok) {
+        int cx, cy;
+        cell_of(g, x, y, cx, cy);
+        // a target outside the points' box starts from the nearest cell of the box: a point in an unvisited cell is still
+        // more than r cells away along one axis, as seen from the target too
+        cx = cx < 0 ? 0 : (cx >= g.nbx ? g.nbx - 1 : cx);
+        cy = cy < 0 ? 0 : (cy >= g.nby ? g.nby - 1 : cy);
+        const double hcell = 1.0 / g.inv_h;
+        int rlast = cx > cy ? cx : cy;                       // ring beyond which every cell has been visited
+        if (g.nbx - 1 - cx > rlast) rlast = g.nbx - 1 - cx;
+        if (g.nby - 1 - cy > rlast) rlast = g.nby - 1 - cy;
+        for (int r = 0; r <= rlast; ++r) {
+            for (int yy = cy - r; yy <= cy + r; ++yy) {
+                if (yy < 0 || yy >= g.nby) continue;
+                const bool edge_row = (yy == cy - r) || (yy == cy + r);
+                const int step = edge_row ? 1 : (2 * r > 0 ? 2 * r : 1);      // interior rows: only the two end cells
+                for (int xx = cx - r; xx <= cx + r; xx += step) {
+                    if (xx < 0 || xx >= g.nbx) continue;
+                    knn_scan_cell<K>(g, hcell, xx, yy, x, y, px, py, start, sorted, bd, id);
+                }
+            }
+            // every unvisited point lies at least r cells away along one axis
+            const double reach = r * hcell * (1.0 - 1e-12);
+            if (id[K - 1] >= 0 && bd[K - 1] < reach * reach) break;
+        }
+        ok = id[K - 1] >= 0;
+    }
+    bool singular = false;
+    double w[N];
+    if (ok) {
+        singular = rbf_factor<K>(x, y, id, px, py, w);
         if (singular) atomicAdd(n_singular, 1);
     }
     for (int f = 0; f < nfields; ++f) {
@@ -649,6 +689,72 @@ __global__ __launch_bounds__(64) void rbf_interp_kernel(const double* __restrict
         }
         out[(int64_t)f * Tn + t] = (T)o;
     }
+}
+
+// Points per block of kSuper x kSuper hash cells (one thread per block; the far check's first level).
+constexpr int kSuper = 8;
+__global__ __launch_bounds__(256) void rbf_super_count_kernel(HashGrid g, const unsigned* __restrict__ start, int nsx, int nsy,
+                                                               unsigned* __restrict__ super_count) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= nsx * nsy) return;
+    const int sx = b % nsx, sy = b / nsx;
+    const int x0 = sx * kSuper, x1 = min(x0 + kSuper, g.nbx);
+    unsigned n = 0;
+    for (int yy = sy * kSuper; yy < min((sy + 1) * kSuper, g.nby); ++yy) n += start[yy * g.nbx + x1] - start[yy * g.nbx + x0];
+    super_count[b] = n;
+}
+
+// The neighbourhoods of the MASKED targets (nn_idx < 0: the nearest point is beyond the mask radius, possibly a whole domain
+// away): found, factored, zero pivots counted, nothing written.  Rings of hash cells around such a target are mostly empty and
+// their number grows with the square of its distance, so the search is two-level instead: the occupied block of 8 x 8 cells
+// nearest to the target first (that bounds the K-th distance well), then every other occupied block that still reaches
+// inside that bound, cell by cell under the same bound.
+template <int K>
+__global__ __launch_bounds__(64) void rbf_far_check_kernel(const double* __restrict__ px, const double* __restrict__ py,
+                                                            const double* __restrict__ tx, const double* __restrict__ ty, int64_t Tn,
+                                                            const int32_t* __restrict__ nn_idx, HashGrid g,
+                                                            const unsigned* __restrict__ start, const int32_t* __restrict__ sorted,
+                                                            const unsigned* __restrict__ super_count, int nsx, int nsy,
+                                                            int* __restrict__ n_singular) {
+    const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (t >= Tn || nn_idx[t] >= 0) return;
+    const double x = tx[t], y = ty[t];
+    if (!(fabs(x) < __builtin_inf() && fabs(y) < __builtin_inf())) return;
+    double bd[K];
+    int32_t id[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) { bd[q] = __builtin_inf(); id[q] = -1; }
+    const double hcell = 1.0 / g.inv_h, hs = hcell * kSuper;
+    auto block_gap2 = [&](int sx, int sy) {            // lower bound of the squared distance to anything in the block
+        const double xlo = sx == 0 ? -__builtin_inf() : g.x0 + (sx - 1e-9) * hs;
+        const double xhi = sx == nsx - 1 ? __builtin_inf() : g.x0 + (sx + 1 + 1e-9) * hs;
+        const double ylo = sy == 0 ? -__builtin_inf() : g.y0 + (sy - 1e-9) * hs;
+        const double yhi = sy == nsy - 1 ? __builtin_inf() : g.y0 + (sy + 1 + 1e-9) * hs;
+        const double gx = fmax(0.0, fmax(xlo - x, x - xhi)), gy = fmax(0.0, fmax(ylo - y, y - yhi));
+        return (gx * gx + gy * gy) * (1.0 - 1e-12);
+    };
+    auto scan_block = [&](int sx, int sy) {
+        for (int yy = sy * kSuper; yy < min((sy + 1) * kSuper, g.nby); ++yy)
+            for (int xx = sx * kSuper; xx < min((sx + 1) * kSuper, g.nbx); ++xx)
+                knn_scan_cell<K>(g, hcell, xx, yy, x, y, px, py, start, sorted, bd, id);
+    };
+    int first = -1;
+    double first_gap = __builtin_inf();
+    for (int b = 0; b < nsx * nsy; ++b) {
+        if (super_count[b] == 0) continue;
+        const double gap = block_gap2(b % nsx, b / nsx);
+        if (gap < first_gap) { first_gap = gap; first = b; }
+    }
+    if (first < 0) return;                              // no finite point at all
+    scan_block(first % nsx, first / nsx);
+    for (int b = 0; b < nsx * nsy; ++b) {
+        if (b == first || super_count[b] == 0) continue;
+        if (block_gap2(b % nsx, b / nsx) > bd[K - 1]) continue;
+        scan_block(b % nsx, b / nsx);
+    }
+    if (id[K - 1] < 0) return;                          // fewer than K finite points: the caller has refused that already
+    double w[K + 3];
+    if (rbf_factor<K>(x, y, id, px, py, w)) atomicAdd(n_singular, 1);
 }
 
 }  // namespace
@@ -790,7 +896,7 @@ __global__ __launch_bounds__(256) void minmax_kernel(const double* __restrict__ 
 // On return start[c]..start[c+1] index `sorted` (point ids of cell c); both live in workspace slot 2.
 static int build_hash(oisat_ctx* h, const double* plon, const double* plat, int64_t P, double cell, HashGrid* g_out,
                       const unsigned** start_out, const int32_t** sorted_out, const double2** sxy_out = nullptr,
-                      const unsigned** scan_error_out = nullptr) {
+                      const unsigned** scan_error_out = nullptr, int max_side = 0) {
     // 1. bounding box of the points
     const int mm_blocks = 64;
     double* mm_dev = (double*)oisat_ws(h, 1, sizeof(double) * 4 * mm_blocks);
@@ -809,6 +915,7 @@ static int build_hash(oisat_ctx* h, const double* plon, const double* plat, int6
     const double spanx = (xmin <= xmax) ? xmax - xmin : 0.0, spany = (ymin <= ymax) ? ymax - ymin : 0.0;
     const int64_t max_cells = 4 * 1024 * 1024;
     while ((floor(spanx / cell) + 1.0) * (floor(spany / cell) + 1.0) > (double)max_cells) cell *= 2.0;
+    if (max_side > 0) cell = fmax(cell, fmax(spanx, spany) / (max_side - 1));           // floor(span / cell) + 1 <= max_side
     HashGrid g;
     g.x0 = (xmin <= xmax) ? xmin : 0.0;
     g.y0 = (ymin <= ymax) ? ymin : 0.0;
@@ -920,6 +1027,18 @@ static int rbf_launch(oisat_ctx* h, int K, const double* plon, const double* pla
     return OISAT_OK;
 }
 
+// The singular-neighbourhood counter and its host copy live behind the 2 KB build_hash uses of the same two buffers.
+static int rbf_counter(oisat_ctx* h, int** flag, int** flag_host, unsigned** table) {
+    char* ws1 = (char*)oisat_ws(h, 1, 8192);
+    char* pin = (char*)oisat_pinned(h, 4096);
+    if (!ws1 || !pin) return OISAT_ENOMEM;
+    *flag = (int*)(ws1 + 2048);
+    *flag_host = (int*)(pin + 2048);
+    *table = (unsigned*)(ws1 + 4096);                    // 1024 block counters
+    HIP_TRY(hipMemsetAsync(*flag, 0, 64, h->stream));
+    return OISAT_OK;
+}
+
 extern "C" int oisat_rbf_interp(oisat_ctx* h, int dtype, const double* plon, const double* plat, int64_t P, const double* tlon,
                                 const double* tlat, int64_t Tn, const int32_t* nn_idx, double cell, int neighbors,
                                 const void* values, int nfields, void* out, int64_t* n_singular) {
@@ -933,10 +1052,10 @@ extern "C" int oisat_rbf_interp(oisat_ctx* h, int dtype, const double* plon, con
     const unsigned* scan_error;
     int rc = build_hash(h, plon, plat, P, cell, &g, &start, &sorted, nullptr, &scan_error);
     if (rc != OISAT_OK) return rc;
-    int* flag = (int*)oisat_ws(h, 1, 64);
-    int* flag_host = (int*)oisat_pinned(h, 64);
-    if (!flag || !flag_host) return OISAT_ENOMEM;
-    HIP_TRY(hipMemsetAsync(flag, 0, 64, h->stream));
+    int *flag, *flag_host;
+    unsigned* table;
+    rc = rbf_counter(h, &flag, &flag_host, &table);
+    if (rc != OISAT_OK) return rc;
     if (dtype == OISAT_F32)
         rc = rbf_launch<float>(h, neighbors, plon, plat, tlon, tlat, Tn, nn_idx, g, start, sorted, values, P, nfields, out, flag);
     else
@@ -946,6 +1065,48 @@ extern "C" int oisat_rbf_interp(oisat_ctx* h, int dtype, const double* plon, con
     HIP_TRY(hipMemcpyAsync(flag_host + 1, scan_error, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (n_singular) *n_singular = flag_host[0];
+    return scan_error_check((const unsigned*)(flag_host + 1));
+}
+
+extern "C" int oisat_rbf_check_masked(oisat_ctx* h, const double* plon, const double* plat, int64_t P, const double* tlon,
+                                      const double* tlat, int64_t Tn, const int32_t* nn_idx, double cell, int neighbors,
+                                      int64_t* n_singular) {
+    ARG_CHECK(h && plon && plat && tlon && tlat && nn_idx && n_singular);
+    ARG_CHECK(P >= 3 && P < (int64_t)INT32_MAX && Tn > 0 && cell > 0.0 && std::isfinite(cell));
+    ARG_CHECK(neighbors >= 3 && neighbors <= 5 && neighbors <= P);
+    HashGrid g;
+    const unsigned* start;
+    const int32_t* sorted;
+    const unsigned* scan_error;
+    // a hash of at most 128 cells a side: 16 x 16 blocks of 8 x 8 cells whatever the extent of the points
+    int rc = build_hash(h, plon, plat, P, cell, &g, &start, &sorted, nullptr, &scan_error, 128);
+    if (rc != OISAT_OK) return rc;
+    int *flag, *flag_host;
+    unsigned* table;
+    rc = rbf_counter(h, &flag, &flag_host, &table);
+    if (rc != OISAT_OK) return rc;
+    const int nsx = (int)cdiv(g.nbx, kSuper), nsy = (int)cdiv(g.nby, kSuper);
+    if (nsx * nsy > 1024) {
+        oisat_set_error("rbf_check_masked: %d x %d blocks", nsx, nsy);
+        return OISAT_EINVAL;
+    }
+    OISAT_LAUNCH(h, "rbf_super_count", rbf_super_count_kernel, dim3((unsigned)cdiv(nsx * nsy, 256)), dim3(256), 0, g, start, nsx, nsy,
+                 table);
+    const dim3 grid((unsigned)cdiv(Tn, 64)), block(64);
+    if (neighbors == 5) {
+        OISAT_LAUNCH(h, "rbf_far_check", rbf_far_check_kernel<5>, grid, block, 0, plon, plat, tlon, tlat, Tn, nn_idx, g, start, sorted,
+                     (const unsigned*)table, nsx, nsy, flag);
+    } else if (neighbors == 4) {
+        OISAT_LAUNCH(h, "rbf_far_check", rbf_far_check_kernel<4>, grid, block, 0, plon, plat, tlon, tlat, Tn, nn_idx, g, start, sorted,
+                     (const unsigned*)table, nsx, nsy, flag);
+    } else {
+        OISAT_LAUNCH(h, "rbf_far_check", rbf_far_check_kernel<3>, grid, block, 0, plon, plat, tlon, tlat, Tn, nn_idx, g, start, sorted,
+                     (const unsigned*)table, nsx, nsy, flag);
+    }
+    HIP_TRY(hipMemcpyAsync(flag_host, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(flag_host + 1, scan_error, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    *n_singular = flag_host[0];
     return scan_error_check((const unsigned*)(flag_host + 1));
 }
 

@@ -20,8 +20,9 @@ on the device for all stacked fields at once (``oisat_linear_interp``).
 Type 3 (``RBFInterpolator(points, Z, neighbors=5)``: thin-plate spline on the 5 nearest pixels): the
 reference solves one 8x8 system per distinct neighbourhood in a Python loop, for every field; here one
 thread per target finds its neighbours, factors the system once and applies the evaluation weights to
-every stacked field (``oisat_rbf_interp``).  Targets the distance mask removes anyway are skipped, so
-a singular neighbourhood raises ``LinAlgError`` only when it feeds an unmasked target.
+every stacked field (``oisat_rbf_interp``).  Targets the distance mask removes anyway get no value, but
+their neighbourhoods are found and factored too (a launch of their own on a coarse point hash), so a
+singular one raises ``LinAlgError`` for the whole call exactly where scipy's evaluate-then-mask does.
 """
 from __future__ import annotations
 
@@ -216,13 +217,20 @@ class TriIndex:
         return out
 
 
-def _rbf(nn: "NNIndex", dt, values_buf, nfields, tgt_buf, T, idx_buf, cell):
-    """``RBFInterpolator(points, values, neighbors=5)`` at the targets whose nearest point lies within ``cell``."""
+def _rbf(nn: "NNIndex", dt, values_buf, nfields, tgt_buf, T, idx_buf, cell, check_masked=True):
+    """``RBFInterpolator(points, values, neighbors=5)`` at the targets whose nearest point lies within ``cell``; the
+    neighbourhoods of the others are factored too (``check_masked``: they do not depend on the values, so once per set of
+    points and targets is enough) and a singular one raises as scipy's evaluation of every target would."""
     ctx = nn.ctx
     if nn.P < 3:                        # scipy: 3 monomials need 3 points
         raise ValueError("At least 3 data points are required when `degree` is 1 and the number of dimensions is 2.")
-    out = ctx.alloc(nfields * T * dt.itemsize)
     nsing = _hip.C.c_int64(0)
+    if check_masked:
+        ctx.check(ctx.lib.oisat_rbf_check_masked(ctx.h, nn.buf.at(0), nn.buf.at(nn.P * 8), nn.P, tgt_buf.at(0), tgt_buf.at(T * 8), T,
+                                                 idx_buf.ptr, float(cell), int(min(5, nn.P)), _hip.C.byref(nsing)))
+        if nsing.value:
+            raise np.linalg.LinAlgError("Singular matrix.")
+    out = ctx.alloc(nfields * T * dt.itemsize)
     ctx.check(ctx.lib.oisat_rbf_interp(ctx.h, _hip.dtype_code(dt), nn.buf.at(0), nn.buf.at(nn.P * 8), nn.P, tgt_buf.at(0),
                                        tgt_buf.at(T * 8), T, idx_buf.ptr, float(cell), int(min(5, nn.P)), values_buf.ptr,
                                        nfields, out.ptr, _hip.C.byref(nsing)))
@@ -422,6 +430,7 @@ class _GranuleRegridder:
         if qhull failed on it; by default it is built here."""
         self.ctx = ctx = _hip.context()
         self.kind = int(interpolator_type)
+        self.rbf_checked = False        # type 3: the masked targets' neighbourhoods are factored with the first field stack only
         self.tri = None
         self.ok = True
         if self.kind == 1:
@@ -494,7 +503,8 @@ class _GranuleRegridder:
         if self.kind == 1:               # targets beyond 2*grid_size of any pixel carry idx -1 -> NaN, like the dists mask
             fine = self.tri.interpolate(dt, masked, nf, self.tgt, self.Tfine, self.idx_fine, self.forced)
         elif self.kind == 3:
-            fine = _rbf(self.nn, dt, masked, nf, self.tgt, self.Tfine, self.idx_fine, self.cell)
+            fine = _rbf(self.nn, dt, masked, nf, self.tgt, self.Tfine, self.idx_fine, self.cell, check_masked=not self.rbf_checked)
+            self.rbf_checked = True
         else:
             fine = _gather(ctx, dt, masked, self.P, nf, self.idx_fine, self.Tfine)
         if self.plan.needed:

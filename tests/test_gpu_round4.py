@@ -442,3 +442,52 @@ def test_interpolator_many_equals_the_serial_calls_bit_for_bit(ctx, capsys):
         if kind == 1:
             assert many[4] is None
     capsys.readouterr()
+
+
+def test_rbf_singular_neighbourhood_of_a_masked_target_raises_as_scipy_does(ctx):
+    """interpolator.py:21-27 evaluates ``RBFInterpolator`` at EVERY target and masks afterwards, so a singular neighbourhood raises
+    ``LinAlgError`` also when its target would have been masked: a regular lattice of points and targets beyond its edge (the five
+    nearest points share a longitude).  The product checks those neighbourhoods in a launch of their own (regrid.hip, FAR)."""
+    import time
+    from scipy.spatial import cKDTree
+    from oisatgmi.interpolator import _interpolosis
+    gx, gy = np.meshgrid(np.arange(12) * 0.25, np.arange(10) * 0.25)
+    lattice = np.column_stack((gx.ravel(), gy.ravel()))
+    Z = np.sin(lattice[:, 0]) + lattice[:, 1]
+    inside = np.random.default_rng(5).uniform([0.05, 0.05], [2.7, 2.2], size=(546, 2))  # inside the lattice, off its symmetry lines
+    X, Y = inside[:, 0].reshape(21, 26), inside[:, 1].reshape(21, 26)                   # (no exact ties for the fifth neighbour)
+    d, _ = cKDTree(lattice).query(np.column_stack((X.ravel(), Y.ravel())))
+    want = orc.interpolosis_rbf(lattice, Z, X, Y, d.reshape(X.shape), 0.25)
+    got = _interpolosis(lattice, Z, X, Y, 3, d.reshape(X.shape), 0.25)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-9 * np.abs(want).max(), equal_nan=True)
+    Xf, Yf = np.meshgrid(np.linspace(-20.0, 20.0, 81), np.linspace(-10.0, 10.0, 41))     # far targets: masked, and singular
+    df, _ = cKDTree(lattice).query(np.column_stack((Xf.ravel(), Yf.ravel())))
+    with pytest.raises(np.linalg.LinAlgError):
+        orc.interpolosis_rbf(lattice, Z, Xf, Yf, df.reshape(Xf.shape), 0.25)
+    with pytest.raises(np.linalg.LinAlgError):
+        _interpolosis(lattice, Z, Xf, Yf, 3, df.reshape(Xf.shape), 0.25)
+    # scattered points: masked targets far away on every side are checked and found regular; the result is the full evaluation's
+    rng = np.random.default_rng(404)
+    pts = rng.uniform(0.0, 3.0, size=(2500, 2))
+    Zs = np.cos(pts[:, 0]) * pts[:, 1]
+    ds, _ = cKDTree(pts).query(np.column_stack((Xf.ravel(), Yf.ravel())))
+    want = orc.interpolosis_rbf(pts, Zs, Xf, Yf, ds.reshape(Xf.shape), 0.1)
+    got = _interpolosis(pts, Zs, Xf, Yf, 3, ds.reshape(Xf.shape), 0.1)
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.isnan(want).any() and np.isfinite(want).any()
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-9 * np.nanmax(np.abs(want)), equal_nan=True)
+    # a granule-sized swath under a global 0.25-degree grid: a million masked targets, up to a hemisphere from the nearest pixel
+    g = syn.swath_granule(8811, nscan=1644, npix=60)
+    sw = np.column_stack((np.ravel(g.longitude_center), np.ravel(g.latitude_center)))
+    glon, glat = np.meshgrid(np.arange(-180.0, 180.0, 0.25) + 0.125, np.arange(-90.0, 90.0, 0.25) + 0.125)
+    dg, _ = cKDTree(sw).query(np.column_stack((glon.ravel(), glat.ravel())))
+    _interpolosis(sw, np.ravel(g.vcd), glon, glat, 3, dg.reshape(glon.shape), 0.125)
+    hctx = _hip.context()
+    hctx.prof_enable(True)
+    hctx.prof_reset()
+    t0 = time.perf_counter()
+    out = _interpolosis(sw, np.ravel(g.vcd), glon, glat, 3, dg.reshape(glon.shape), 0.125)
+    dt = time.perf_counter() - t0
+    rec = {k: round(v["total_ms"], 3) for k, v in hctx.prof_collect().items() if k.startswith("rbf")}
+    hctx.prof_enable(False)
+    print(f"global type-3 call {dt * 1e3:.1f} ms; kernels {rec}; finite targets {int(np.isfinite(out).sum())}")
+    assert np.isfinite(out).any() and rec.get("rbf_far_check", 0.0) < 200.0
