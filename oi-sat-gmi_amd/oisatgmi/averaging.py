@@ -56,12 +56,9 @@ def error_averager(error_X: np.ndarray):
 
 
 def averaging(startdate: str, enddate: str, reader_obj):
-    '''
-          average the data
-          Input:
-              startdate [str]: starting date in YYYY-mm-dd format string
-              enddate [str]: ending date in YYYY-mm-dd format string
-    '''
+    """Drop-in for ``averaging`` (averaging.py:26-120): the per-granule satellite and model columns of ``reader_obj`` between
+    the two dates (``'YYYY-mm-dd'`` strings, the end exclusive) reduced to monthly means on the model grid: ``nanmean`` of the
+    columns and auxiliaries, ``error_averager`` of the errors.  The stacks are reduced on the device (csrc/averaging.hip)."""
     ctx = _hip.context()
     start_date = datetime.date(int(startdate[0:4]), int(startdate[5:7]), int(startdate[8:10]))
     end_date = datetime.date(int(enddate[0:4]), int(enddate[5:7]), int(enddate[8:10]))

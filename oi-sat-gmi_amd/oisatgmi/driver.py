@@ -37,12 +37,8 @@ class oisatgmi(object):
 
     # ---- hot path ---------------------------------------------------------------------------
     def average(self, startdate: str, enddate: str, gasname=None):
-        '''
-            average the data
-            Input:
-                startdate [str]: starting date in YYYY-mm-dd format string
-                enddate [str]: ending date in YYYY-mm-dd format string
-        '''
+        """Monthly means of what the reader holds between the two ``'YYYY-mm-dd'`` dates (driver.py:53-70); ``gasname='O3'``
+        additionally converts the model column to Dobson units."""
         (self.sat_averaged_vcd, self.sat_averaged_error, self.ctm_averaged_vcd, self.aux1, self.aux2,
          self.avg_time) = averaging(startdate, enddate, self.reader_obj)
         if gasname == 'O3':
@@ -194,8 +190,7 @@ class oisatgmi(object):
         '''
         Write the final results to a netcdf (same variable names, types and dimensions as the reference,
         driver.py:156-227).  Uses netCDF4 when it is installed; otherwise SciPy's NetCDF-3 writer.
-        ARGS:
-            output_file (char): the name of file to be outputted
+        ``output_file``: file name without the extension; ``output_folder`` is created when missing.
         '''
         if not os.path.exists(output_folder):
             os.makedirs(output_folder)

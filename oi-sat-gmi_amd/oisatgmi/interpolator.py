@@ -355,16 +355,14 @@ def _upscale_plan(X, Y, ctm_models_coordinate, grid_size, threshold):
 
 def _upscaler(X: np.ndarray, Y: np.ndarray, Z: np.ndarray, ctm_models_coordinate: dict, grid_size: float,
               threshold: float, tri=None, error=False):
-    '''
-        upscaler function (interpolator.py:48-97)
-        Input:
-            X [2D]: x coordinates of the input (Z)
-            Y [2D]: y coordinates of the input (Z)
-            Z [2D]: Z values
-            ctm_models_coordinate [dic]: a dictionary containing lat and lon of the model
-            grid_size [float]: the size of grids defined by the user
-            threshold [float]: any points with distance above this will be masked
-    '''
+    """Drop-in for ``_upscaler`` (interpolator.py:48-97): when the model cells are at least as wide as the regridding cells,
+    average the fine field over the footprint of a model cell (a box mean, or for ``error=True`` the variance of that mean)
+    and pick the value at the fine node nearest to every model cell centre.
+
+    ``X``, ``Y``, ``Z`` are the fine grid's coordinates and the field on it (2-D, same shape); ``ctm_models_coordinate`` holds
+    the model's ``'Latitude'`` / ``'Longitude'`` meshes; ``grid_size`` is the fine spacing in degrees; model cells farther than
+    ``threshold`` from every fine node come back NaN.  ``tri`` is accepted for signature compatibility and unused, as in the
+    reference.  Returns ``(lon, lat, field, False)``, or the inputs with ``True`` when no upscaling is needed."""
     plan = _upscale_plan(X, Y, ctm_models_coordinate, grid_size, threshold)
     if not plan.needed:
         return X, Y, Z, True
@@ -567,19 +565,14 @@ def interpolator_many(interpolator_type: int, grid_size: float, granules, ctm_mo
 
 
 def interpolator(interpolator_type: int, grid_size: float, sat_data, ctm_models_coordinate: dict, flag_thresh=0.75):
-    '''
-        The interpolator function (interpolator.py:100-291)
-        Input:
-            interpolator_type [int]: an index specifying the type of interpolator
-                    1 > Bilinear interpolation (Delaunay, recommended)
-                    2 > Nearest neighbour
-                    3 > RBF (thin_plate_spline)
-                    4 > KDtree (fast nearest neighbour)
-            grid_size [float]: the size of grids defined by the user
-            sat_data  [satellite_amf or satellite_opt]: a dataclass for satellite data
-            ctm_models_coordinate [dic]: a dictionary containing lat and lon of the model
-            flag_thresh [float]: the quality flag threshold
-    '''
+    """Drop-in for ``interpolator`` (interpolator.py:100-291): one satellite granule onto the model grid.
+
+    ``interpolator_type`` picks the scheme between swath pixels and the regular ``grid_size``-degree grid laid over the model
+    region: 1 = linear on a Delaunay triangulation (what the reference recommends), 2 = nearest pixel, 3 = thin-plate-spline
+    RBF on the five nearest pixels, 4 = nearest pixel by k-d tree (same answer as 2).  ``sat_data`` is a ``satellite_amf`` or
+    ``satellite_opt`` record; pixels whose quality flag is at or below ``flag_thresh`` are masked before regridding.
+    ``ctm_models_coordinate`` holds the model's ``'Latitude'`` / ``'Longitude'`` meshes.  Returns a record of the same type on
+    the model grid, or ``None`` when the granule misses the region or cannot be triangulated."""
     return _interpolate_granule(interpolator_type, grid_size, sat_data, ctm_models_coordinate, flag_thresh, _NOT_GIVEN)
 
 
