@@ -258,6 +258,24 @@ int oisat_rbf_interp(oisat_ctx* h, int dtype, const double* plon, const double* 
                      const double* tlon, const double* tlat, int64_t T, const int32_t* nn_idx, double cell,
                      int neighbors, const void* values, int nfields, void* out, int64_t* n_singular);
 
+/* oisat_rbf_interp that also reports the targets whose K-th neighbour is not unique (the runner-up is exactly as near):
+ * which of the candidates RBFInterpolator's own KDTree(y).query(x, K) returns is a property of scipy's tree, and a regular
+ * lattice of points (an L3 product) produces such targets wholesale.  tie_list: dev int32[T], *n_ties (host) entries filled,
+ * in no particular order; their values in `out` come from the lowest-index choice and their zero pivots are NOT in
+ * *n_singular -- send them through oisat_rbf_interp_forced with the neighbours the host's tree names. */
+int oisat_rbf_interp_ties(oisat_ctx* h, int dtype, const double* plon, const double* plat, int64_t P,
+                          const double* tlon, const double* tlat, int64_t T, const int32_t* nn_idx, double cell,
+                          int neighbors, const void* values, int nfields, void* out, int64_t* n_singular,
+                          int32_t* tie_list, int64_t* n_ties);
+
+/* Type-3 evaluation of n listed targets on neighbourhoods given by the caller: targets dev int32[n] (indices into the T
+ * targets), ids dev int32[n * neighbors] (point indices, any order; an entry outside [0, P) leaves that target as it is).
+ * Overwrites out[f * T + target] for every field; *n_singular (host, may be NULL) = zero pivots among them. */
+int oisat_rbf_interp_forced(oisat_ctx* h, int dtype, const double* plon, const double* plat, int64_t P,
+                            const double* tlon, const double* tlat, int64_t T, const int32_t* targets,
+                            const int32_t* ids, int64_t n, int neighbors, const void* values, int nfields, void* out,
+                            int64_t* n_singular);
+
 /* The other half of interpolator.py:21-27: scipy evaluates RBFInterpolator at EVERY target and masks afterwards,
  * so a singular neighbourhood raises LinAlgError for the whole call even when its target is masked (a regular
  * lattice of points and a target beyond its edge: five collinear neighbours).  For the targets with nn_idx < 0:

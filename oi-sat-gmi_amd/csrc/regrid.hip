@@ -635,17 +635,18 @@ __global__ __launch_bounds__(64) void rbf_interp_kernel(const double* __restrict
                                                          const int32_t* __restrict__ nn_idx, HashGrid g,
                                                          const unsigned* __restrict__ start, const int32_t* __restrict__ sorted,
                                                          const T* __restrict__ values, int64_t P, int nfields, T* __restrict__ out,
-                                                         int* __restrict__ n_singular) {
+                                                         int* __restrict__ n_singular, int32_t* __restrict__ tie_list,
+                                                         unsigned* __restrict__ n_ties) {
     constexpr int N = K + 3;
     const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (t >= Tn) return;
     bool ok = nn_idx[t] >= 0;
     const double x = tx[t], y = ty[t];
     ok = ok && x == x && y == y;
-    double bd[K];
-    int32_t id[K];
+    double bd[K + 1];                                        // the K neighbours and the runner-up
+    int32_t idk[K + 1];
 #pragma unroll
-    for (int q = 0; q < K; ++q) { bd[q] = __builtin_inf(); id[q] = -1; }
+    for (int q = 0; q <= K; ++q) { bd[q] = __builtin_inf(); idk[q] = -1; }
     if (ok) {
         int cx, cy;
         cell_of(g, x, y, cx, cy);
@@ -664,24 +665,65 @@ __global__ __launch_bounds__(64) void rbf_interp_kernel(const double* __restrict
                 const int step = edge_row ? 1 : (2 * r > 0 ? 2 * r : 1);      // interior rows: only the two end cells
                 for (int xx = cx - r; xx <= cx + r; xx += step) {
                     if (xx < 0 || xx >= g.nbx) continue;
-                    knn_scan_cell<K>(g, hcell, xx, yy, x, y, px, py, start, sorted, bd, id);
+                    knn_scan_cell<K + 1>(g, hcell, xx, yy, x, y, px, py, start, sorted, bd, idk);
                 }
             }
             // every unvisited point lies at least r cells away along one axis
             const double reach = r * hcell * (1.0 - 1e-12);
-            if (id[K - 1] >= 0 && bd[K - 1] < reach * reach) break;
+            if (idk[K] >= 0 && bd[K] < reach * reach) break;
         }
-        ok = id[K - 1] >= 0;
+        ok = idk[K - 1] >= 0;
     }
+    // the runner-up as near as the K-th neighbour: which of them scipy's tree returns is its traversal's business; the host
+    // asks that tree and sends the target through rbf_forced_kernel
+    const bool tie = ok && tie_list && idk[K] >= 0 && bd[K] == bd[K - 1];
+    if (tie) tie_list[atomicAdd(n_ties, 1u)] = (int32_t)t;
+    int32_t id[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) id[q] = idk[q];
     bool singular = false;
     double w[N];
     if (ok) {
         singular = rbf_factor<K>(x, y, id, px, py, w);
-        if (singular) atomicAdd(n_singular, 1);
+        if (singular && !tie) atomicAdd(n_singular, 1);
     }
     for (int f = 0; f < nfields; ++f) {
         double o = __builtin_nan("");
         if (ok && !singular) {
+            const T* vf = values + (int64_t)f * P;
+            o = 0.0;
+#pragma unroll
+            for (int q = 0; q < K; ++q) o += w[q] * (double)vf[id[q]];
+        }
+        out[(int64_t)f * Tn + t] = (T)o;
+    }
+}
+
+// Targets whose neighbourhood the host dictates (ids[i * K ..], from scipy's own tree: exact ties for the K-th neighbour).
+template <typename T, int K>
+__global__ __launch_bounds__(64) void rbf_forced_kernel(const double* __restrict__ px, const double* __restrict__ py,
+                                                         const double* __restrict__ tx, const double* __restrict__ ty, int64_t Tn,
+                                                         const int32_t* __restrict__ targets, const int32_t* __restrict__ ids, int64_t n,
+                                                         const T* __restrict__ values, int64_t P, int nfields, T* __restrict__ out,
+                                                         int* __restrict__ n_singular) {
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t t = targets[i];
+    if (t < 0 || t >= Tn) return;
+    int32_t id[K];
+    bool ok = true;
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+        id[q] = ids[i * K + q];
+        ok = ok && id[q] >= 0 && id[q] < P;
+    }
+    if (!ok) return;
+    double w[K + 3];
+    const bool singular = rbf_factor<K>(tx[t], ty[t], id, px, py, w);
+    if (singular) atomicAdd(n_singular, 1);
+    for (int f = 0; f < nfields; ++f) {
+        double o = __builtin_nan("");
+        if (!singular) {
             const T* vf = values + (int64_t)f * P;
             o = 0.0;
 #pragma unroll
@@ -1012,22 +1054,41 @@ extern "C" int oisat_nn_query_ties(oisat_ctx* h, const double* plon, const doubl
 template <typename T>
 static int rbf_launch(oisat_ctx* h, int K, const double* plon, const double* plat, const double* tlon, const double* tlat,
                       int64_t Tn, const int32_t* nn_idx, HashGrid g, const unsigned* start, const int32_t* sorted, const void* values,
-                      int64_t P, int nfields, void* out, int* flag) {
+                      int64_t P, int nfields, void* out, int* flag, int32_t* tie_list, unsigned* n_ties) {
     const dim3 grid((unsigned)cdiv(Tn, 64)), block(64);
     if (K == 5) {
         OISAT_LAUNCH(h, "rbf_interp", (rbf_interp_kernel<T, 5>), grid, block, 0, plon, plat, tlon, tlat, Tn, nn_idx, g, start, sorted,
-                     (const T*)values, P, nfields, (T*)out, flag);
+                     (const T*)values, P, nfields, (T*)out, flag, tie_list, n_ties);
     } else if (K == 4) {
         OISAT_LAUNCH(h, "rbf_interp", (rbf_interp_kernel<T, 4>), grid, block, 0, plon, plat, tlon, tlat, Tn, nn_idx, g, start, sorted,
-                     (const T*)values, P, nfields, (T*)out, flag);
+                     (const T*)values, P, nfields, (T*)out, flag, tie_list, n_ties);
     } else {
         OISAT_LAUNCH(h, "rbf_interp", (rbf_interp_kernel<T, 3>), grid, block, 0, plon, plat, tlon, tlat, Tn, nn_idx, g, start, sorted,
+                     (const T*)values, P, nfields, (T*)out, flag, tie_list, n_ties);
+    }
+    return OISAT_OK;
+}
+
+template <typename T>
+static int rbf_forced_launch(oisat_ctx* h, int K, const double* plon, const double* plat, const double* tlon, const double* tlat,
+                             int64_t Tn, const int32_t* targets, const int32_t* ids, int64_t n, const void* values, int64_t P,
+                             int nfields, void* out, int* flag) {
+    const dim3 grid((unsigned)cdiv(n, 64)), block(64);
+    if (K == 5) {
+        OISAT_LAUNCH(h, "rbf_forced", (rbf_forced_kernel<T, 5>), grid, block, 0, plon, plat, tlon, tlat, Tn, targets, ids, n,
+                     (const T*)values, P, nfields, (T*)out, flag);
+    } else if (K == 4) {
+        OISAT_LAUNCH(h, "rbf_forced", (rbf_forced_kernel<T, 4>), grid, block, 0, plon, plat, tlon, tlat, Tn, targets, ids, n,
+                     (const T*)values, P, nfields, (T*)out, flag);
+    } else {
+        OISAT_LAUNCH(h, "rbf_forced", (rbf_forced_kernel<T, 3>), grid, block, 0, plon, plat, tlon, tlat, Tn, targets, ids, n,
                      (const T*)values, P, nfields, (T*)out, flag);
     }
     return OISAT_OK;
 }
 
-// The singular-neighbourhood counter and its host copy live behind the 2 KB build_hash uses of the same two buffers.
+// The singular-neighbourhood counter (+ the tie counter behind it) and their host copy live behind the 2 KB build_hash
+// uses of the same two buffers.
 static int rbf_counter(oisat_ctx* h, int** flag, int** flag_host, unsigned** table) {
     char* ws1 = (char*)oisat_ws(h, 1, 8192);
     char* pin = (char*)oisat_pinned(h, 4096);
@@ -1039,9 +1100,9 @@ static int rbf_counter(oisat_ctx* h, int** flag, int** flag_host, unsigned** tab
     return OISAT_OK;
 }
 
-extern "C" int oisat_rbf_interp(oisat_ctx* h, int dtype, const double* plon, const double* plat, int64_t P, const double* tlon,
-                                const double* tlat, int64_t Tn, const int32_t* nn_idx, double cell, int neighbors,
-                                const void* values, int nfields, void* out, int64_t* n_singular) {
+static int rbf_interp_impl(oisat_ctx* h, int dtype, const double* plon, const double* plat, int64_t P, const double* tlon,
+                           const double* tlat, int64_t Tn, const int32_t* nn_idx, double cell, int neighbors, const void* values,
+                           int nfields, void* out, int64_t* n_singular, int32_t* tie_list, int64_t* n_ties) {
     ARG_CHECK(h && plon && plat && tlon && tlat && nn_idx && values && out);
     ARG_CHECK(P >= 3 && P < (int64_t)INT32_MAX && Tn > 0 && nfields > 0 && cell > 0.0 && std::isfinite(cell));
     ARG_CHECK(neighbors >= 3 && neighbors <= 5 && neighbors <= P);
@@ -1056,16 +1117,59 @@ extern "C" int oisat_rbf_interp(oisat_ctx* h, int dtype, const double* plon, con
     unsigned* table;
     rc = rbf_counter(h, &flag, &flag_host, &table);
     if (rc != OISAT_OK) return rc;
+    unsigned* ties_dev = (unsigned*)(flag + 1);
     if (dtype == OISAT_F32)
-        rc = rbf_launch<float>(h, neighbors, plon, plat, tlon, tlat, Tn, nn_idx, g, start, sorted, values, P, nfields, out, flag);
+        rc = rbf_launch<float>(h, neighbors, plon, plat, tlon, tlat, Tn, nn_idx, g, start, sorted, values, P, nfields, out, flag,
+                               tie_list, ties_dev);
     else
-        rc = rbf_launch<double>(h, neighbors, plon, plat, tlon, tlat, Tn, nn_idx, g, start, sorted, values, P, nfields, out, flag);
+        rc = rbf_launch<double>(h, neighbors, plon, plat, tlon, tlat, Tn, nn_idx, g, start, sorted, values, P, nfields, out, flag,
+                                tie_list, ties_dev);
     if (rc != OISAT_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(flag_host, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipMemcpyAsync(flag_host + 1, scan_error, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(flag_host, flag, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(flag_host + 2, scan_error, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (n_singular) *n_singular = flag_host[0];
-    return scan_error_check((const unsigned*)(flag_host + 1));
+    if (n_ties) *n_ties = (int64_t)(unsigned)flag_host[1];
+    return scan_error_check((const unsigned*)(flag_host + 2));
+}
+
+extern "C" int oisat_rbf_interp(oisat_ctx* h, int dtype, const double* plon, const double* plat, int64_t P, const double* tlon,
+                                const double* tlat, int64_t Tn, const int32_t* nn_idx, double cell, int neighbors,
+                                const void* values, int nfields, void* out, int64_t* n_singular) {
+    return rbf_interp_impl(h, dtype, plon, plat, P, tlon, tlat, Tn, nn_idx, cell, neighbors, values, nfields, out, n_singular,
+                           nullptr, nullptr);
+}
+
+extern "C" int oisat_rbf_interp_ties(oisat_ctx* h, int dtype, const double* plon, const double* plat, int64_t P, const double* tlon,
+                                     const double* tlat, int64_t Tn, const int32_t* nn_idx, double cell, int neighbors,
+                                     const void* values, int nfields, void* out, int64_t* n_singular, int32_t* tie_list,
+                                     int64_t* n_ties) {
+    ARG_CHECK(tie_list && n_ties);
+    return rbf_interp_impl(h, dtype, plon, plat, P, tlon, tlat, Tn, nn_idx, cell, neighbors, values, nfields, out, n_singular,
+                           tie_list, n_ties);
+}
+
+extern "C" int oisat_rbf_interp_forced(oisat_ctx* h, int dtype, const double* plon, const double* plat, int64_t P,
+                                       const double* tlon, const double* tlat, int64_t Tn, const int32_t* targets,
+                                       const int32_t* ids, int64_t n, int neighbors, const void* values, int nfields, void* out,
+                                       int64_t* n_singular) {
+    ARG_CHECK(h && plon && plat && tlon && tlat && targets && ids && values && out);
+    ARG_CHECK(P >= 3 && P < (int64_t)INT32_MAX && Tn > 0 && n > 0 && n <= Tn && nfields > 0);
+    ARG_CHECK(neighbors >= 3 && neighbors <= 5 && neighbors <= P);
+    ARG_CHECK(dtype == OISAT_F32 || dtype == OISAT_F64);
+    int *flag, *flag_host;
+    unsigned* table;
+    int rc = rbf_counter(h, &flag, &flag_host, &table);
+    if (rc != OISAT_OK) return rc;
+    if (dtype == OISAT_F32)
+        rc = rbf_forced_launch<float>(h, neighbors, plon, plat, tlon, tlat, Tn, targets, ids, n, values, P, nfields, out, flag);
+    else
+        rc = rbf_forced_launch<double>(h, neighbors, plon, plat, tlon, tlat, Tn, targets, ids, n, values, P, nfields, out, flag);
+    if (rc != OISAT_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(flag_host, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (n_singular) *n_singular = flag_host[0];
+    return OISAT_OK;
 }
 
 extern "C" int oisat_rbf_check_masked(oisat_ctx* h, const double* plon, const double* plat, int64_t P, const double* tlon,

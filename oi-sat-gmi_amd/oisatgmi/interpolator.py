@@ -74,6 +74,7 @@ class NNIndex:
         self.P = lon.size
         self.lon, self.lat = lon, lat
         self._tree = None
+        self._rbf_tree = None
         self.ties_resolved = 0
         self.buf = self.ctx.alloc(2 * self.P * 8)
         self.ctx.upload_into(self.buf.at(0), lon)
@@ -97,6 +98,14 @@ class NNIndex:
             from scipy.spatial import cKDTree
             self._tree = cKDTree(np.column_stack((self.lon, self.lat)))
         return self._tree
+
+    def rbf_tree(self):
+        """``KDTree(points)``: the class and defaults ``RBFInterpolator`` builds its own neighbour tree with (not ``cKDTree``:
+        the leaf size differs, and with it the pick among equidistant candidates)."""
+        if self._rbf_tree is None:
+            from scipy.spatial import KDTree
+            self._rbf_tree = KDTree(np.column_stack((self.lon, self.lat)))
+        return self._rbf_tree
 
     def query_device(self, tlon, tlat, max_dist, want_dist=False, resolve_ties=True):
         """-> (DeviceBuffer int32[T] of point indices (-1 = beyond max_dist), dist buffer or None)"""
@@ -217,25 +226,60 @@ class TriIndex:
         return out
 
 
-def _rbf(nn: "NNIndex", dt, values_buf, nfields, tgt_buf, T, idx_buf, cell, check_masked=True):
-    """``RBFInterpolator(points, values, neighbors=5)`` at the targets whose nearest point lies within ``cell``; the
-    neighbourhoods of the others are factored too (``check_masked``: they do not depend on the values, so once per set of
-    points and targets is enough) and a singular one raises as scipy's evaluation of every target would."""
+class _RbfTies:
+    """Targets whose fifth neighbour is not unique, with the neighbourhoods scipy's own tree gives them: found with the first
+    field stack of a (points, targets) pair, reused by the later ones."""
+
+    def __init__(self):
+        self.known = False
+        self.n = 0
+        self.targets = None
+        self.ids = None
+
+
+def _rbf(nn: "NNIndex", dt, values_buf, nfields, tgt_buf, T, idx_buf, cell, memo=None):
+    """``RBFInterpolator(points, values, neighbors=5)`` at the targets whose nearest point lies within ``cell``.
+
+    Two things scipy's evaluate-everything-then-mask does are kept although the masked targets get no value here: their
+    neighbourhoods are factored too, so that a singular one raises (``oisat_rbf_check_masked``), and where the fifth neighbour
+    of an unmasked target is not unique the choice is the one ``RBFInterpolator``'s own ``KDTree(points).query(x, 5)`` makes
+    (``oisat_rbf_interp_ties`` reports those targets, the host asks the tree, ``oisat_rbf_interp_forced`` evaluates them).
+    Neither depends on the values: ``memo`` (a ``_RbfTies``) carries both over to further field stacks of the same pair."""
     ctx = nn.ctx
     if nn.P < 3:                        # scipy: 3 monomials need 3 points
         raise ValueError("At least 3 data points are required when `degree` is 1 and the number of dimensions is 2.")
+    K = int(min(5, nn.P))
+    code = _hip.dtype_code(dt)
+    px, py, tx, ty = nn.buf.at(0), nn.buf.at(nn.P * 8), tgt_buf.at(0), tgt_buf.at(T * 8)
     nsing = _hip.C.c_int64(0)
-    if check_masked:
-        ctx.check(ctx.lib.oisat_rbf_check_masked(ctx.h, nn.buf.at(0), nn.buf.at(nn.P * 8), nn.P, tgt_buf.at(0), tgt_buf.at(T * 8), T,
-                                                 idx_buf.ptr, float(cell), int(min(5, nn.P)), _hip.C.byref(nsing)))
+    memo = memo if memo is not None else _RbfTies()
+    if not memo.known:
+        ctx.check(ctx.lib.oisat_rbf_check_masked(ctx.h, px, py, nn.P, tx, ty, T, idx_buf.ptr, float(cell), K, _hip.C.byref(nsing)))
         if nsing.value:
             raise np.linalg.LinAlgError("Singular matrix.")
     out = ctx.alloc(nfields * T * dt.itemsize)
-    ctx.check(ctx.lib.oisat_rbf_interp(ctx.h, _hip.dtype_code(dt), nn.buf.at(0), nn.buf.at(nn.P * 8), nn.P, tgt_buf.at(0),
-                                       tgt_buf.at(T * 8), T, idx_buf.ptr, float(cell), int(min(5, nn.P)), values_buf.ptr,
-                                       nfields, out.ptr, _hip.C.byref(nsing)))
+    ties = ctx.alloc(T * 4)
+    nties = _hip.C.c_int64(0)
+    ctx.check(ctx.lib.oisat_rbf_interp_ties(ctx.h, code, px, py, nn.P, tx, ty, T, idx_buf.ptr, float(cell), K, values_buf.ptr,
+                                            nfields, out.ptr, _hip.C.byref(nsing), ties.ptr, _hip.C.byref(nties)))
     if nsing.value:
         raise np.linalg.LinAlgError("Singular matrix.")
+    if not memo.known:
+        memo.known = True
+        memo.n = int(nties.value)
+        if memo.n:
+            which = np.sort(ctx.download(ties.ptr, (memo.n,), _I32))
+            xy = ctx.download(tgt_buf.ptr, (2, T), _F64)[:, which].T
+            _, pick = nn.rbf_tree().query(xy, K)
+            memo.targets = ctx.upload(which, dtype=_I32)
+            memo.ids = ctx.upload(np.ascontiguousarray(pick.reshape(memo.n, K), dtype=np.int32), dtype=_I32)
+            nn.ties_resolved += memo.n
+    ties.free()
+    if memo.n:
+        ctx.check(ctx.lib.oisat_rbf_interp_forced(ctx.h, code, px, py, nn.P, tx, ty, T, memo.targets.ptr, memo.ids.ptr, memo.n, K,
+                                                  values_buf.ptr, nfields, out.ptr, _hip.C.byref(nsing)))
+        if nsing.value:
+            raise np.linalg.LinAlgError("Singular matrix.")
     return out
 
 
@@ -428,7 +472,7 @@ class _GranuleRegridder:
         if qhull failed on it; by default it is built here."""
         self.ctx = ctx = _hip.context()
         self.kind = int(interpolator_type)
-        self.rbf_checked = False        # type 3: the masked targets' neighbourhoods are factored with the first field stack only
+        self.rbf_memo = _RbfTies()      # type 3: what does not depend on the values is found with the first field stack only
         self.tri = None
         self.ok = True
         if self.kind == 1:
@@ -501,8 +545,7 @@ class _GranuleRegridder:
         if self.kind == 1:               # targets beyond 2*grid_size of any pixel carry idx -1 -> NaN, like the dists mask
             fine = self.tri.interpolate(dt, masked, nf, self.tgt, self.Tfine, self.idx_fine, self.forced)
         elif self.kind == 3:
-            fine = _rbf(self.nn, dt, masked, nf, self.tgt, self.Tfine, self.idx_fine, self.cell, check_masked=not self.rbf_checked)
-            self.rbf_checked = True
+            fine = _rbf(self.nn, dt, masked, nf, self.tgt, self.Tfine, self.idx_fine, self.cell, memo=self.rbf_memo)
         else:
             fine = _gather(ctx, dt, masked, self.P, nf, self.idx_fine, self.Tfine)
         if self.plan.needed:

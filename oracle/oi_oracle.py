@@ -294,7 +294,8 @@ def interpolosis_rbf(pts, Z, X, Y, dists, threshold, neighbors=5, only_unmasked=
     keep = ~(np.ravel(dists) > threshold * 2.0) if only_unmasked else np.ones(tgt.shape[0], dtype=bool)
     if keep.any():
         x = tgt[keep]
-        _, nb = _cKDTree(pts).query(x, k)
+        from scipy.spatial import KDTree                              # RBFInterpolator's own tree class (leafsize 10): among
+        _, nb = KDTree(pts).query(x, k)                               # equidistant candidates it is this tree's pick that counts
         nb = np.sort(nb.reshape(x.shape[0], k), axis=1)
         y = pts[nb]                                                   # (T, k, 2)
         mins, maxs = y.min(axis=1), y.max(axis=1)

@@ -242,6 +242,30 @@ def gen_interpolator_rbf():
     save("interpolator_rbf.npz", **out)
 
 
+def gen_interpolator_rbf_ties():
+    """_interpolosis type 3 on a regular lattice of points (an L3 product): targets on the lattice's symmetry lines are
+    equidistant from several candidates for the fifth neighbour, and which one RBFInterpolator's ``KDTree(y).query(x, 5)``
+    returns is a property of scipy's tree.  Three target sets: cell centres (four-fold ties), the lattice nodes themselves,
+    and a 0.1-degree mesh that mixes tied and untied targets; all inside the lattice (beyond its edge the five neighbours
+    are collinear and the call raises)."""
+    from scipy.spatial import cKDTree
+    gx, gy = np.meshgrid(10.0 + 0.25 * np.arange(14), -5.0 + 0.25 * np.arange(12))
+    pts = np.column_stack((gx.ravel(), gy.ravel()))
+    Z = np.sin(0.9 * gx) * np.cos(1.3 * gy) + 0.05 * gx
+    out = {"points": pts, "Z": Z}
+    sets = {
+        "centres": np.meshgrid(10.125 + 0.25 * np.arange(13), -4.875 + 0.25 * np.arange(11)),
+        "nodes": np.meshgrid(10.0 + 0.25 * np.arange(14), -5.0 + 0.25 * np.arange(12)),
+        "mesh": np.meshgrid(10.05 + 0.1 * np.arange(32), -4.95 + 0.1 * np.arange(27)),
+    }
+    for tag, (X, Y) in sets.items():
+        dists, _ = cKDTree(pts).query(np.column_stack((X.ravel(), Y.ravel())))
+        dists = dists.reshape(X.shape)
+        out[f"{tag}_X"], out[f"{tag}_Y"], out[f"{tag}_dists"] = X, Y, dists
+        out[f"{tag}_out"] = REF_interp._interpolosis(pts, Z, X, Y, 3, dists, 0.25)
+    save("interpolator_rbf_ties.npz", **out)
+
+
 def gen_interpolator_levels():
     """interpolator() on records that carry per-level cubes: the satellite_amf scattering-weight / pressure loops
     (interpolator.py:191-213) and both satellite_opt branches -- MOPITT (nz+1 averaging-kernel rows, no pressure weights)
@@ -463,6 +487,9 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["rbf"]:                   # only the (slow) type-3 file
         gen_interpolator_rbf()
         raise SystemExit(0)
+    if sys.argv[1:] == ["rbfties"]:
+        gen_interpolator_rbf_ties()
+        raise SystemExit(0)
     if sys.argv[1:] == ["akconv"]:
         gen_ak_conv()
         raise SystemExit(0)
@@ -488,6 +515,7 @@ if __name__ == "__main__":
     gen_upscaler()
     gen_interpolator()
     gen_interpolator_rbf()
+    gen_interpolator_rbf_ties()
     gen_interpolator_levels()
     gen_linear_degenerate()
     gen_upscaler_ties()

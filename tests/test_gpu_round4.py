@@ -491,3 +491,21 @@ def test_rbf_singular_neighbourhood_of_a_masked_target_raises_as_scipy_does(ctx)
     hctx.prof_enable(False)
     print(f"global type-3 call {dt * 1e3:.1f} ms; kernels {rec}; finite targets {int(np.isfinite(out).sum())}")
     assert np.isfinite(out).any() and rec.get("rbf_far_check", 0.0) < 200.0
+
+
+def test_rbf_on_a_lattice_picks_the_neighbours_scipys_tree_picks(ctx, golden):
+    """tests/golden/interpolator_rbf_ties.npz: the reference's ``_interpolosis(points, Z, X, Y, 3, ...)`` on a regular lattice of
+    points, where the fifth neighbour of most targets is one of several equidistant candidates (interpolator.py:21-27 ->
+    ``RBFInterpolator`` -> ``KDTree(y).query(x, 5)``).  The device reports those targets and the host's tree names their
+    neighbours; without that step the lowest-index choice differs from the reference by up to 0.6 % of the field."""
+    from oisatgmi.interpolator import _interpolosis, NNIndex
+    g = golden("interpolator_rbf_ties.npz")
+    for tag in ("centres", "nodes", "mesh"):
+        want = g[f"{tag}_out"]
+        nn = NNIndex.from_any(g["points"])
+        got = _interpolosis(nn, g["Z"], g[f"{tag}_X"], g[f"{tag}_Y"], 3, g[f"{tag}_dists"], 0.25)
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-10 * np.abs(want).max(), equal_nan=True)
+        print(tag, "targets", want.size, "with a tie for the fifth neighbour", nn.ties_resolved)
+        assert nn.ties_resolved > 0
+    got32 = _interpolosis(g["points"], g["Z"].astype(np.float32), g["mesh_X"], g["mesh_Y"], 3, g["mesh_dists"], 0.25)
+    np.testing.assert_allclose(got32, g["mesh_out"], rtol=0, atol=2e-6 * np.abs(g["mesh_out"]).max())

@@ -259,6 +259,16 @@ def test_interpolator_type3_rbf(golden):
         np.testing.assert_allclose(o, g["single_out"], rtol=0, atol=1e-12 * np.nanmax(np.abs(g["single_out"])), equal_nan=True)
 
 
+def test_interpolator_type3_rbf_on_a_lattice_follows_scipys_tree(golden):
+    """Points on a regular lattice: many targets are equidistant from several candidates for the fifth neighbour, and the
+    reference's answer is whichever one ``RBFInterpolator``'s own ``KDTree(y)`` returns (interpolator.py:21-27)."""
+    g = golden("interpolator_rbf_ties.npz")
+    for tag in ("centres", "nodes", "mesh"):
+        want = g[f"{tag}_out"]
+        got = orc.interpolosis_rbf(g["points"], g["Z"], g[f"{tag}_X"], g[f"{tag}_Y"], g[f"{tag}_dists"], 0.25)
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-12 * np.abs(want).max(), equal_nan=True)
+
+
 @pytest.mark.parametrize("tag", ["m_eccoh", "m_gmi64", "m_up", "g_eccoh", "g_gmi64", "g_up"])
 def test_ak_conv(golden, tag):
     """ak_conv_mopitt / ak_conv_gosat restatement against the reference's own outputs."""
