@@ -263,6 +263,20 @@ def gen_interpolator_rbf_ties():
         dists = dists.reshape(X.shape)
         out[f"{tag}_X"], out[f"{tag}_Y"], out[f"{tag}_dists"] = X, Y, dists
         out[f"{tag}_out"] = REF_interp._interpolosis(pts, Z, X, Y, 3, dists, 0.25)
+    # interpolator(3, ...) on a level-3 lattice record (per-level cubes: several field stacks over one set of neighbourhoods)
+    for sensor, seed, grid in (("MOPITT", 6201, "gs100_1x125"), ("GOSAT", 6202, "gs100_2x25")):
+        la0, la1, lo0, lo1, dlat, dlon, gs = TIE_GRIDS[grid]
+        ctm = syn.regional_ctm_grid(la0, la1, lo0, lo1, dlat, dlon)
+        out[f"{grid}_clat"], out[f"{grid}_clon"] = ctm["Latitude"], ctm["Longitude"]
+        r = quiet(REF_interp.interpolator, 3, gs, to_ref(syn.lattice_l3_granule(seed, sensor=sensor)), ctm, 0.0)
+        assert r is not None
+        names = []
+        for f in dataclasses.fields(r):
+            v = getattr(r, f.name)
+            if isinstance(v, np.ndarray):
+                out[f"l3_{sensor}_{grid}_t3_{f.name}"] = v
+                names.append(f.name)
+        out[f"l3_{sensor}_{grid}_t3_arrays"] = np.array(names)
     save("interpolator_rbf_ties.npz", **out)
 
 

@@ -509,3 +509,15 @@ def test_rbf_on_a_lattice_picks_the_neighbours_scipys_tree_picks(ctx, golden):
         assert nn.ties_resolved > 0
     got32 = _interpolosis(g["points"], g["Z"].astype(np.float32), g["mesh_X"], g["mesh_Y"], 3, g["mesh_dists"], 0.25)
     np.testing.assert_allclose(got32, g["mesh_out"], rtol=0, atol=2e-6 * np.abs(g["mesh_out"]).max())
+
+
+@pytest.mark.parametrize("sensor,seed,grid", [("MOPITT", 6201, "gs100_1x125"), ("GOSAT", 6202, "gs100_2x25")])
+def test_interpolator_type3_on_lattice_l3_records_matches_reference(ctx, golden, sensor, seed, grid):
+    """interpolator(3, ...) on level-3 lattice records against the reference's own output (per-level cubes: the tied targets
+    and their neighbourhoods are found with the first field stack and reused by the others)."""
+    from test_oracle_golden import check_l3_rbf_record
+    from oisatgmi.interpolator import interpolator
+    g = golden("interpolator_rbf_ties.npz")
+    ctm = {"Latitude": g[f"{grid}_clat"], "Longitude": g[f"{grid}_clon"]}
+    r = interpolator(3, 1.0, syn.lattice_l3_granule(seed, sensor=sensor), ctm, 0.0)
+    check_l3_rbf_record(g, sensor, grid, r, 1e-10)

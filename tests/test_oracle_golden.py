@@ -269,6 +269,34 @@ def test_interpolator_type3_rbf_on_a_lattice_follows_scipys_tree(golden):
         np.testing.assert_allclose(got, want, rtol=0, atol=1e-12 * np.abs(want).max(), equal_nan=True)
 
 
+L3_RBF_CASES = [("MOPITT", 6201, "gs100_1x125"), ("GOSAT", 6202, "gs100_2x25")]
+
+
+def check_l3_rbf_record(g, sensor, grid, r, tol):
+    """every array of the record against the reference's, to ``tol`` of the field's range (a thin-plate system on lattice
+    points is conditioned ~1e3: LAPACK's and another elimination order differ by ~1e-13)"""
+    assert isinstance(r, cfg.satellite_opt)
+    for name in g[f"l3_{sensor}_{grid}_t3_arrays"]:
+        want = g[f"l3_{sensor}_{grid}_t3_{name}"]
+        got = np.asarray(getattr(r, str(name)))
+        if want.shape == (1,):
+            assert got.shape == (1,)
+            continue
+        assert got.shape == want.shape, (sensor, grid, name)
+        assert np.array_equal(np.isnan(got), np.isnan(want)), (sensor, grid, name)
+        np.testing.assert_allclose(got, want, rtol=0, atol=tol * np.nanmax(np.abs(want)), equal_nan=True, err_msg=f"{sensor} {grid} {name}")
+
+
+@pytest.mark.parametrize("sensor,seed,grid", L3_RBF_CASES)
+def test_interpolator_type3_on_lattice_l3_records(golden, sensor, seed, grid):
+    """interpolator(3, ...) on level-3 lattice records: every fine node is the centre of four lattice points and has
+    several equidistant candidates for its fifth neighbour."""
+    g = golden("interpolator_rbf_ties.npz")
+    ctm = {"Latitude": g[f"{grid}_clat"], "Longitude": g[f"{grid}_clon"]}
+    r = orc.interpolator(3, 1.0, syn.lattice_l3_granule(seed, sensor=sensor), ctm, 0.0, record_type=cfg.satellite_opt)
+    check_l3_rbf_record(g, sensor, grid, r, 1e-11)
+
+
 @pytest.mark.parametrize("tag", ["m_eccoh", "m_gmi64", "m_up", "g_eccoh", "g_gmi64", "g_up"])
 def test_ak_conv(golden, tag):
     """ak_conv_mopitt / ak_conv_gosat restatement against the reference's own outputs."""
