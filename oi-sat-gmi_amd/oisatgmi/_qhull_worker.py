@@ -3,12 +3,19 @@
 Started as ``python -m oisatgmi._qhull_worker`` (a child process with pipes -- not multiprocessing: "spawn" re-imports the
 caller's main script, and the reference's run/job.py has no ``__main__`` guard; "fork" must not be used from a process
 that holds a GPU context).  Protocol, both ways: 8-byte little-endian length, then a pickle.  Request: ``(lon, lat)``
-float arrays of the pixel centres; reply: the ``scipy.spatial.Delaunay`` of them as the reference builds it
-(interpolator.py:151-155) with ``transform`` / ``vertex_to_simplex`` / ``neighbors`` filled in, or ``None`` when qhull
-fails.  Ends at end of input.  Never imports the HIP binding or torch."""
+float arrays of the pixel centres; reply: ``("ok", tri)`` with the ``scipy.spatial.Delaunay`` of them as the reference builds
+it (interpolator.py:151-155), ``transform`` / ``vertex_to_simplex`` / ``neighbors`` filled in, or ``("failed", None)`` when
+qhull refuses the points (the reference then skips the granule).  A reply that never comes -- the pipe at end of file --
+means the worker died, which is an error and not a skipped granule.  Ends at end of input.  Never loads the HIP library or
+torch; whatever a library prints goes to stderr, the reply pipe carries replies only."""
+import os
 import pickle
 import struct
 import sys
+
+
+class WorkerDied(RuntimeError):
+    pass
 
 
 def triangulate(lon, lat):
@@ -38,13 +45,26 @@ def write_msg(f, obj):
     f.flush()
 
 
+def reply_of(f):
+    """The parent's side of one exchange: the triangulation, ``None`` if qhull failed, ``WorkerDied`` at end of file."""
+    msg = read_msg(f)
+    if msg is None:
+        raise WorkerDied("a triangulation worker ended without replying")
+    status, tri = msg
+    return tri if status == "ok" else None
+
+
 def main():
-    fin, fout = sys.stdin.buffer, sys.stdout.buffer
+    fin = sys.stdin.buffer
+    fout = os.fdopen(os.dup(sys.stdout.fileno()), "wb")     # the reply pipe, out of reach of print()
+    os.dup2(sys.stderr.fileno(), sys.stdout.fileno())
+    sys.stdout = sys.stderr
     while True:
         req = read_msg(fin)
         if req is None:
             return
-        write_msg(fout, triangulate(*req))
+        tri = triangulate(*req)
+        write_msg(fout, ("ok", tri) if tri is not None else ("failed", None))
 
 
 if __name__ == "__main__":

@@ -446,8 +446,11 @@ class _QhullWorkers:
         def call():
             with self.locks[k]:
                 p = self.procs[k]
-                w.write_msg(p.stdin, (np.asarray(lon), np.asarray(lat)))
-                return w.read_msg(p.stdout)
+                try:
+                    w.write_msg(p.stdin, (np.asarray(lon), np.asarray(lat)))
+                    return w.reply_of(p.stdout)
+                except (w.WorkerDied, BrokenPipeError, OSError) as e:     # not "qhull failed": that is a reply
+                    raise RuntimeError(f"triangulation worker {k} (pid {p.pid}) died, exit code {p.poll()}: {e}") from e
         return executor.submit(call)
 
     def close(self):

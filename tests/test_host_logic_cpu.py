@@ -290,3 +290,32 @@ def test_bench_launcher_propagates_a_failing_rank_and_refuses_a_mismatched_launc
     # under a launcher that started another number of ranks than --gpus says: refused before anything touches a GPU
     r = _run_bench("--gpus", "2", "--launcher-selftest", "0", env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "must agree" in (r.stderr + r.stdout)
+
+
+def test_triangulation_worker_protocol_tells_a_failure_from_a_death():
+    """interpolator_many's child processes (oisatgmi/_qhull_worker.py): a triangulation comes back with its lazily computed
+    members, points qhull refuses come back as ``None`` (the reference skips such a granule, interpolator.py:151-155), stray
+    prints do not reach the reply pipe, and a worker that is gone raises instead of reading as "qhull failed"."""
+    import subprocess
+    import sys
+    from oisatgmi import _qhull_worker as w
+    from oisatgmi.interpolator import _QhullWorkers
+    from concurrent.futures import ThreadPoolExecutor
+    rng = np.random.default_rng(0)
+    lon, lat = rng.uniform(size=400), rng.uniform(size=400)
+    procs = _QhullWorkers(2)
+    try:
+        with ThreadPoolExecutor(max_workers=2) as ex:
+            tri = procs.submit(ex, lon, lat).result(timeout=120)
+            flat = procs.submit(ex, np.arange(12.0), np.zeros(12)).result(timeout=120)
+            from scipy.spatial import Delaunay
+            want = Delaunay(np.column_stack((lon, lat)))
+            assert np.array_equal(tri.simplices, want.simplices) and np.array_equal(tri.transform, want.transform, equal_nan=True)
+            assert flat is None
+            for p in procs.procs:
+                p.kill()
+                p.wait()
+            with pytest.raises(RuntimeError, match="triangulation worker .* died"):
+                procs.submit(ex, lon, lat).result(timeout=120)
+    finally:
+        procs.close()
