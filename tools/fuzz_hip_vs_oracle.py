@@ -211,15 +211,70 @@ def fuzz_amf_recal(rng):
             close(getattr(a, f), getattr(b, f), 1e-11 if f64 else 1e-5, "amf_recal " + f, p)
 
 
+def fuzz_dense(rng):
+    """The dense Gaussian-B analysis (no reference code: the oracle is the float64 restatement) on random small months."""
+    from oisatgmi import dense, _hip
+    ny, nx = [(18, 36), (36, 72), (45, 90), (72, 144)][int(rng.integers(0, 4))]
+    m = int(rng.choice([0, 1, 3, 60, 127, 128, 129, 300, 700, 1500]))
+    L = float(np.exp(rng.uniform(np.log(80.0), np.log(3000.0))))
+    species = str(rng.choice(["NO2", "HCHO", "O3"]))
+    seed = int(rng.integers(1, 10 ** 6))
+    swaths = bool(rng.integers(0, 2)) and m >= 60
+    p = syn.point_obs_case(ny, nx, max(m, 1), seed, swaths=swaths, species=species)
+    olat, olon, y, var = p.obs_lat[:m].copy(), p.obs_lon[:m].copy(), p.obs_y[:m].copy(), p.obs_var[:m].copy()
+    m = olat.size
+    how = str(rng.choice(["plain", "duplicates", "cluster", "small_R", "large_R"]))
+    if m >= 3 and how == "duplicates":
+        k = max(1, m // 4)
+        olat[:k], olon[:k] = olat[-k:], olon[-k:]
+    elif m >= 3 and how == "cluster":
+        olat = 10.0 + 3.0 * rng.normal(size=m)
+        olon = 20.0 + 3.0 * rng.normal(size=m)
+    elif how == "small_R":
+        var = var * 0.05
+    elif how == "large_R":
+        var = var * 50.0
+    dt = np.float64 if rng.integers(0, 2) else np.float32
+    prm = dict(ny=ny, nx=nx, m=m, L=round(L, 1), species=species, seed=seed, swaths=swaths, how=how, dt=np.dtype(dt).name)
+    cell = dense.regular_grid_cell(p.lat, p.lon, olat, olon)
+    try:
+        xb, inc, info = dense.OI_dense(p.Xa, None, p.Sa, None, p.lat, p.lon, L, refine=3, dtype=dt, obs=dict(lat=olat, lon=olon, y=y, var=var))
+    except _hip.OisatError as e:
+        # an honest refusal (not positive definite in float32 / refinement above tolerance) is an answer; a wrong field is not
+        msg = str(e)
+        if "refinement tolerance" in msg or "positive definite" in msg:
+            prm["refused"] = msg[:60]
+            REFUSED.append(prm)
+            return
+        BAD.append(("dense raised", prm, msg[:200]))
+        return
+    ref = orc.dense_oi(p.lat, p.lon, p.Xa, p.Sa, olat, olon, cell, np.where(y < 0, 0, y), var, L)
+    tol = 1e-5                                   # north_star's bound (the refinement stops at a 1e-6 residual: ill-conditioned
+    scale = np.abs(ref["xa"]).max()              # months -- tiny R, clustered observations, long L -- reach 4e-6 of the field scale)
+    CHECKS[0] += 2
+    for nm, a, b in (("xa", xb.ravel(), ref["xa"]), ("inc", inc.ravel(), ref["inc"])):
+        err = np.abs(a - b).max() if a.size else 0.0
+        WORST[0] = max(WORST[0], err / scale)
+        if not np.array_equal(np.isnan(a), np.isnan(b)) or err > tol * scale:
+            BAD.append(("dense " + nm, prm, f"max abs diff {err:.3e} = {err / scale:.2e} of scale"))
+
+
+REFUSED = []
+WORST = [0.0]
+
+
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 20261005)
     for name, fn, mult in (("OI", fuzz_oi, 3), ("error_averager", fuzz_error_averager, 5), ("averaging", fuzz_averaging, 1), ("upscaler", fuzz_upscaler, 2),
-                           ("interpolator", fuzz_interpolator, 1), ("amf_recal", fuzz_amf_recal, 2)):
+                           ("interpolator", fuzz_interpolator, 1), ("amf_recal", fuzz_amf_recal, 2), ("dense", fuzz_dense, 2)):
         before, checks = len(BAD), CHECKS[0]
         for _ in range(rounds * mult):
             fn(rng)
         print(f"{name}: {rounds * mult} cases, {CHECKS[0] - checks} arrays compared, {len(BAD) - before} mismatching", flush=True)
+    print(f"dense: worst field error {WORST[0]:.2e} of the field scale (bound 1e-5), {len(REFUSED)} refusals")
+    for prm in REFUSED:
+        print("refused (counted as an answer):", prm)
     for what, params, msg in BAD[:60]:
         print("MISMATCH", what, msg, params)
     return min(len(BAD), 255)
