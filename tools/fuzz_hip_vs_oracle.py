@@ -215,7 +215,7 @@ def fuzz_dense(rng):
     """The dense Gaussian-B analysis (no reference code: the oracle is the float64 restatement) on random small months."""
     from oisatgmi import dense, _hip
     ny, nx = [(18, 36), (36, 72), (45, 90), (72, 144)][int(rng.integers(0, 4))]
-    m = int(rng.choice([0, 1, 3, 60, 127, 128, 129, 300, 700, 1500]))
+    m = int(rng.choice([0, 1, 3, 60, 127, 128, 129, 300, 700, 1500, 2100, 4200, 6100]))     # (the larger ones reach the task graph)
     L = float(np.exp(rng.uniform(np.log(80.0), np.log(3000.0))))
     species = str(rng.choice(["NO2", "HCHO", "O3"]))
     seed = int(rng.integers(1, 10 ** 6))
