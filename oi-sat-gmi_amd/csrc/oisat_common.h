@@ -142,6 +142,7 @@ struct oisat_ctx {
     // pinned host scratch for small synchronous read-backs
     void* pinned = nullptr;
     size_t pinned_bytes = 0;
+    hipStream_t xfer_streams[4] = {nullptr, nullptr, nullptr, nullptr};   // oisat_d2h: slices of a large read-back, one host thread each
 };
 
 #define HIP_TRY(expr)                                                                          \

@@ -525,8 +525,8 @@ class _GranuleRegridder:
         return b
 
     def regrid(self, fields, error=False):
-        """``fields``: list of swath-shaped arrays.  Returns (X, Y, [Z per field], upscaled_ctm_needed),
-        each Z = _upscaler(.., _interpolosis(tri, field*mask, ..), .., error=error)[2]."""
+        """``fields``: list of swath-shaped arrays.  Returns (X, Y, Z, upscaled_ctm_needed) with Z of shape (fields, ny, nx),
+        Z[f] = _upscaler(.., _interpolosis(tri, field*mask, ..), .., error=error)[2]."""
         ctx = self.ctx
         nf = len(fields)
         dt = _regrid_dtype()
@@ -560,7 +560,7 @@ class _GranuleRegridder:
             Z = ctx.download(fine.ptr, (nf,) + tuple(self.fine_shape), dt)
             X, Y = self.lons_grid, self.lats_grid
             need = True
-        return X, Y, [Z[f] for f in range(nf)], need
+        return X, Y, Z, need            # Z[f] = field f (one array: consecutive fields are a cube without a copy)
 
 
 def interpolator_many(interpolator_type: int, grid_size: float, granules, ctm_models_coordinate: dict, flag_thresh=0.75, workers=None):
@@ -686,15 +686,15 @@ def _interpolate_granule(interpolator_type, grid_size, sat_data, ctm_models_coor
             return None
     by_name = dict(zip(names, Z))
 
-    def cube(name):
-        first, count = levels[name]
-        return np.stack(Z[first:first + count]).astype(np.float64, copy=False)
+    def cube(name):                     # the levels were regridded as consecutive fields: their block of Z is the cube
+        first, count = levels[name]     # (np.stack of 35 global float64 fields was 21 ms a cube, half of a type-4 call)
+        return Z[first:first + count].astype(np.float64, copy=False)
 
     tropopause = by_name["tropopause"] if has_trop else np.empty((1))
     latitude_center = upscaled_Y
     longitude_center = upscaled_X
     print('....................... error')
-    _, _, (uncertainty,), _ = rg.regrid([sat_data.uncertainty], error=True)       # variance kernel, :185-187
+    uncertainty = rg.regrid([sat_data.uncertainty], error=True)[2][0]             # variance kernel, :185-187
     uncertainty = np.sqrt(uncertainty)                                           # :188
 
     if is_amf:
