@@ -224,6 +224,16 @@ int oisat_linear_interp(oisat_ctx* h, int dtype, const double* tlon, const doubl
                         const int32_t* neighbors, const double* transform, int64_t nsimplex,
                         const void* values, int64_t P, int nfields, void* out, const double* bounds_host);
 
+/* scipy's Delaunay.transform on the device (the host computes it with three LAPACK calls per simplex: 0.55-1.0 s for the
+ * 197,000 simplices of an OMI granule, more than qhull).  points: dev double[P][2] as Delaunay.points; simplices: dev
+ * int32[nsimplex][3]; transform_out: dev double[nsimplex][3][2] = (T^-1 rows, r_2), NaN for a simplex whose 2 x 2 matrix
+ * is singular or has a 1-norm condition number above 1 / (1000 eps), as scipy marks it.  Same elimination order as LAPACK's
+ * (the values agree with scipy's to the last bit on the build host).  suspects (dev int32[nsimplex]) receives, in no
+ * particular order, the simplices within four orders of magnitude of that limit or singular, *n_suspect (host) how many:
+ * scipy's own decision and values for exactly those are a call of its routine on that subset (interpolator.py host side). */
+int oisat_tri_transform(oisat_ctx* h, const double* points, int64_t P, const int32_t* simplices, int64_t nsimplex,
+                        double* transform_out, int32_t* suspects, int64_t* n_suspect);
+
 /* Targets whose location in the triangulation is NOT unique: amb_list (dev int32[T], no particular order) receives the
  * ids of the targets for which a second simplex accepts the point as well (it lies on a shared facet or vertex to within
  * scipy's eps) or whose walk had to fall back to the brute-force scan; *n_amb (host) = how many.  scipy evaluates targets

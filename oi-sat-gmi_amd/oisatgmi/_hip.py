@@ -78,6 +78,7 @@ SIGNATURES = {
                                              C.c_int, _ptr, C.POINTER(C.c_double), _ptr]),
     "oisat_rbf_interp": (C.c_int, [_c_ctx, C.c_int, _ptr, _ptr, _i64, _ptr, _ptr, _i64, _ptr, C.c_double, C.c_int, _ptr, C.c_int,
                                    _ptr, C.POINTER(C.c_int64)]),
+    "oisat_tri_transform": (C.c_int, [_c_ctx, _ptr, _i64, _ptr, _i64, _ptr, _ptr, C.POINTER(C.c_int64)]),
     "oisat_rbf_interp_ties": (C.c_int, [_c_ctx, C.c_int, _ptr, _ptr, _i64, _ptr, _ptr, _i64, _ptr, C.c_double, C.c_int, _ptr, C.c_int,
                                         _ptr, C.POINTER(C.c_int64), _ptr, C.POINTER(C.c_int64)]),
     "oisat_rbf_interp_forced": (C.c_int, [_c_ctx, C.c_int, _ptr, _ptr, _i64, _ptr, _ptr, _i64, _ptr, _ptr, _i64, C.c_int, _ptr,

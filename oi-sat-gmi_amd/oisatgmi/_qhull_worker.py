@@ -4,7 +4,7 @@ Started as ``python -m oisatgmi._qhull_worker`` (a child process with pipes -- n
 caller's main script, and the reference's run/job.py has no ``__main__`` guard; "fork" must not be used from a process
 that holds a GPU context).  Protocol, both ways: 8-byte little-endian length, then a pickle.  Request: ``(lon, lat)``
 float arrays of the pixel centres; reply: ``("ok", tri)`` with the ``scipy.spatial.Delaunay`` of them as the reference builds
-it (interpolator.py:151-155), ``transform`` / ``vertex_to_simplex`` / ``neighbors`` filled in, or ``("failed", None)`` when
+it (interpolator.py:151-155), ``vertex_to_simplex`` / ``neighbors`` filled in, or ``("failed", None)`` when
 qhull refuses the points (the reference then skips the granule).  A reply that never comes -- the pipe at end of file --
 means the worker died, which is an error and not a skipped granule.  Ends at end of input.  Never loads the HIP library or
 torch; whatever a library prints goes to stderr, the reply pipe carries replies only."""
@@ -24,7 +24,8 @@ def triangulate(lon, lat):
     pts = np.column_stack((np.ravel(lon), np.ravel(lat))).astype(np.float64)
     try:
         tri = Delaunay(pts)
-        tri.transform, tri.vertex_to_simplex, tri.neighbors      # noqa: B018 -- lazily computed members, carried by the pickle
+        tri.vertex_to_simplex, tri.neighbors      # noqa: B018 -- lazily computed members, carried by the pickle (the barycentric
+        #                                           transforms are the device's job: oisat_tri_transform)
         return tri
     except Exception:
         return None

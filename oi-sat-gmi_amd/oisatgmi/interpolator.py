@@ -14,9 +14,10 @@ underneath (nearest-neighbour types 2 and 4 first):
   cells pick (interpolator.py:72-91 filters the whole fine grid and throws most of it away).
 
 Type 1 (Delaunay linear, the reference's "recommended" default): the triangulation is built by
-qhull on the host exactly as the reference does (``Delaunay(points)``, interpolator.py:153); point
-location and barycentric evaluation -- what ``LinearNDInterpolator`` repeats for every field -- run
-on the device for all stacked fields at once (``oisat_linear_interp``).
+qhull on the host exactly as the reference does (``Delaunay(points)``, interpolator.py:153); its
+barycentric transforms (``Delaunay.transform``: more host time than qhull itself), point location and
+barycentric evaluation -- what ``LinearNDInterpolator`` repeats for every field -- run on the device
+for all stacked fields at once (``oisat_tri_transform``, ``oisat_linear_interp``).
 Type 3 (``RBFInterpolator(points, Z, neighbors=5)``: thin-plate spline on the 5 nearest pixels): the
 reference solves one 8x8 system per distinct neighbourhood in a Python loop, for every field; here one
 thread per target finds its neighbours, factors the system once and applies the evaluation weights to
@@ -161,13 +162,50 @@ class TriIndex:
         self.ns = int(tri.simplices.shape[0])
         self.simplices = ctx.upload(tri.simplices, dtype=np.int32)
         self.neighbors = ctx.upload(tri.neighbors, dtype=np.int32)
-        self.transform = ctx.upload(tri.transform, dtype=np.float64)
         self.v2s = ctx.upload(tri.vertex_to_simplex, dtype=np.int32)
         self.P = int(tri.points.shape[0])
         self.ambiguous = 0
-        self.has_degenerate = bool(np.isnan(tri.transform[:, 0, 0]).any())
+        self._barycentric_transforms()
         self.bounds = (_hip.C.c_double * 4)(float(tri.min_bound[0]), float(tri.max_bound[0]), float(tri.min_bound[1]),
                                              float(tri.max_bound[1]))
+
+    def _barycentric_transforms(self):
+        """``Delaunay.transform`` without its host cost (three LAPACK calls per simplex under the GIL: 0.55-1.0 s per OMI
+        granule, more than qhull): ``oisat_tri_transform`` walks the same 2 x 2 elimination per simplex on the device; the
+        simplices it reports as close to scipy's degeneracy limit are handed to scipy's own routine, so which simplices are
+        NaN is always scipy's decision.  A triangulation that already carries its transform (a worker computed it) keeps it."""
+        ctx, tri = self.ctx, self.tri
+        have = getattr(tri, "_transform", self)            # scipy's private cache of the lazily computed property
+        if have is self or have is not None:               # another scipy layout, or the transform is there already: take scipy's
+            have = tri.transform
+            self.transform = ctx.upload(have, dtype=np.float64)
+            self.has_degenerate = bool(np.isnan(have[:, 0, 0]).any())
+            return
+        pts = ctx.upload(tri.points, dtype=np.float64)
+        self.transform = ctx.alloc(self.ns * 6 * 8)
+        suspects = ctx.alloc(self.ns * 4)
+        n = _hip.C.c_int64(0)
+        ctx.check(ctx.lib.oisat_tri_transform(ctx.h, pts.ptr, self.P, self.simplices.ptr, self.ns, self.transform.ptr, suspects.ptr,
+                                              _hip.C.byref(n)))
+        self.has_degenerate = False
+        if n.value:
+            from scipy.spatial import _qhull
+            which = np.sort(ctx.download(suspects.ptr, (int(n.value),), _I32))
+            rows = _qhull._get_barycentric_transforms(tri.points, np.ascontiguousarray(tri.simplices[which]), np.finfo(np.float64).eps)
+            host = ctx.download(self.transform.ptr, (self.ns, 3, 2), _F64)
+            host[which] = rows
+            ctx.upload_into(self.transform.at(0), host)
+            self.has_degenerate = bool(np.isnan(rows[:, 0, 0]).any())
+            tri._transform = host
+        pts.free()
+        suspects.free()
+
+    def host_transform(self):
+        """The triangulation with its transform filled in from the device copy (``find_simplex`` would otherwise compute its
+        own on the host, and then not necessarily the very same last bits the device evaluates with)."""
+        if getattr(self.tri, "_transform", self) is None:
+            self.tri._transform = self.ctx.download(self.transform.ptr, (self.ns, 3, 2), _F64)
+        return self.tri
 
     @classmethod
     def from_points(cls, lon, lat):
@@ -191,7 +229,7 @@ class TriIndex:
             # qhull closed the hull with zero-area simplices (NaN transforms): the triangulation is then not a partition
             # -- large flat simplices overlap their neighbours -- and "the" simplex of a target is whatever the sequential
             # search returns, for any target.  Take all of them from it.
-            found = self.tri.find_simplex(np.column_stack((np.ravel(tlon), np.ravel(tlat))).astype(np.float64))
+            found = self.host_transform().find_simplex(np.column_stack((np.ravel(tlon), np.ravel(tlat))).astype(np.float64))
             self.ambiguous = int(T)
             return ctx.upload(found.astype(np.int32))
         amb = ctx.alloc(T * 4)
@@ -206,7 +244,7 @@ class TriIndex:
             return None
         which = np.sort(ctx.download(amb.ptr, (int(n.value),), _I32))
         amb.free()
-        found = self.tri.find_simplex(np.column_stack((np.ravel(tlon), np.ravel(tlat))).astype(np.float64))
+        found = self.host_transform().find_simplex(np.column_stack((np.ravel(tlon), np.ravel(tlat))).astype(np.float64))
         forced = np.full(T, -2, dtype=np.int32)
         forced[which] = found[which]
         return ctx.upload(forced)

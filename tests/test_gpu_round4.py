@@ -521,3 +521,29 @@ def test_interpolator_type3_on_lattice_l3_records_matches_reference(ctx, golden,
     ctm = {"Latitude": g[f"{grid}_clat"], "Longitude": g[f"{grid}_clon"]}
     r = interpolator(3, 1.0, syn.lattice_l3_granule(seed, sensor=sensor), ctm, 0.0)
     check_l3_rbf_record(g, sensor, grid, r, 1e-10)
+
+
+def test_barycentric_transforms_on_the_device_are_scipys(ctx, golden):
+    """``oisat_tri_transform`` against ``Delaunay.transform`` (what LinearNDInterpolator evaluates with, interpolator.py:12-15,
+    :151-159): a jittered swath (values to the last bits: same elimination order as LAPACK's), a lattice, and the degenerate
+    fixture, where the NaN simplices must be exactly scipy's (the ones near its condition limit are scipy's own call)."""
+    from scipy.spatial import Delaunay
+    from oisatgmi.interpolator import TriIndex
+    g = syn.swath_granule(4411, nscan=600, npix=60)
+    cases = {"swath": np.column_stack((np.ravel(g.longitude_center), np.ravel(g.latitude_center))).astype(np.float64),
+             "degenerate": golden("interpolator_degenerate.npz")["pts"]}
+    l3 = syn.lattice_l3_granule(6201)
+    cases["lattice"] = np.column_stack((np.ravel(l3.longitude_center), np.ravel(l3.latitude_center))).astype(np.float64)
+    for tag, pts in cases.items():
+        want = Delaunay(pts).transform
+        tri = Delaunay(pts)
+        ti = TriIndex(tri)
+        assert tag == "degenerate" or tri._transform is None          # nothing computed on the host for a healthy triangulation
+        got = ctx.download(ti.transform.ptr, want.shape, np.float64)
+        assert np.array_equal(np.isnan(got), np.isnan(want)), tag
+        ok = ~np.isnan(want[:, 0, 0])
+        same = float((got[ok] == want[ok]).all(axis=(1, 2)).mean())
+        print(f"{tag}: {ok.sum()} simplices, {int((~ok).sum())} degenerate, bitwise equal to scipy {same:.4f}")
+        np.testing.assert_allclose(got[ok], want[ok], rtol=1e-12, atol=0)
+        assert ti.has_degenerate == bool((~ok).any())
+    assert bool(np.isnan(Delaunay(cases["degenerate"]).transform).any())
