@@ -425,8 +425,8 @@ def regrid_leg(ctx, sync):
         dt = time.perf_counter() - t0
         out[f"type{it}_s_per_granule"] = dt
         out[f"type{it}_fields_per_s"] = 73 / dt
-    # a month's loop over granules (reader.py:1405): type 1 with the triangulations of the granules ahead built by host threads
-    # while the device regrids the current one (interpolator_many) -- amortised over 32 granules of that size
+    # a month's loop over granules (reader.py:1405): type 1 with the triangulations of the granules ahead built by worker
+    # processes while the device regrids the current one (interpolator_many) -- amortised over 32 granules of that size
     from oisatgmi.interpolator import interpolator_many
     many = []
     for k in range(32):
@@ -441,8 +441,9 @@ def regrid_leg(ctx, sync):
         sync()
     dt = time.perf_counter() - t0
     out["type1_many_s_per_granule"] = dt / len(many)
-    out["type1_many"] = {"granules": len(many), "seconds": dt, "regridded": sum(r is not None for r in res), "host_threads": min(8, len(os.sched_getaffinity(0))),
-                         "note": "interpolator_many: qhull for the granules ahead on host threads, device regrid of the current one; outputs bit-identical to the serial calls"}
+    out["type1_many"] = {"granules": len(many), "seconds": dt, "regridded": sum(r is not None for r in res),
+                         "worker_processes": max(1, min(8, len(os.sched_getaffinity(0)) - 1, len(many))),
+                         "note": "interpolator_many: qhull for the granules ahead in worker processes, barycentric transforms and regrid of the current one on the device; outputs bit-identical to the serial calls"}
     return out
 
 
