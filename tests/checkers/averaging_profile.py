@@ -1,7 +1,7 @@
 """averaging() end to end (host records in, host fields out) on a month of 30 granules at 720x1440, against the oracle on this host.
-usage (GPU box): python tools/averaging_profile.py"""
+usage (GPU box): python tests/checkers/averaging_profile.py"""
 import contextlib, io, os, sys, time, cProfile, pstats
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "oi-sat-gmi_amd")]
 import numpy as np
 from oisatgmi import synthetic as syn, config as cfg

@@ -2,7 +2,7 @@
 """Random small cases through the HIP path and through the oracle (the checker), side by side -- the GPU-side twin of
 tests/golden/fuzz_oracle_vs_reference.py.  Run on the GPU box:
 
-    gpurun -- python tools/fuzz_hip_vs_oracle.py [rounds] [seed]
+    gpurun -- python tests/checkers/fuzz_hip_vs_oracle.py [rounds] [seed]
 
 A bug hunt, not a test: the pinned cases live in tests/; what this finds becomes a fixture or a test there."""
 import dataclasses
@@ -13,7 +13,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "oi-sat-gmi_amd"))
 sys.path.insert(0, ROOT)
 from oisatgmi import synthetic as syn, config as cfg                  # noqa: E402

@@ -1,6 +1,6 @@
 """profiling aid: field error of the dense analysis against the float64 oracle as a function of the refinement tolerance"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "oi-sat-gmi_amd")]
 import numpy as np
 from oracle import oi_oracle as orc
