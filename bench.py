@@ -911,6 +911,10 @@ def main():
             "parity_anchor": "dense Gaussian-B path: no reference code exists (SURVEY 8 a-ext); oracle = float64 SciPy Cholesky of the "
                              "same definition, reference-anchored only in the L -> 0 limit against OI() golden outputs (DESIGN section 2)",
         }
+    if rank == 0 and world > 1 and not args.no_roofline:
+        # the dominant kernel's roofline on rank 0 of a multi-GPU run too (the other ranks wait at the next leg's barrier): the
+        # launch is per GPU, so the fraction is this GPU's -- the other legs below stay single-GPU extras
+        out["roofline"], out["kernel_ms_per_step"] = roofline_leg(ctx, plan, L, refine, 2 if m > 30000 else 5)
     if rank == 0 and world == 1:
         if not args.no_roofline:
             out["roofline"], out["kernel_ms_per_step"] = roofline_leg(ctx, plan, L, refine, 2 if m > 30000 else 5)
