@@ -123,7 +123,7 @@ def fuzz_upscaler(rng):
 
 
 def fuzz_interpolator(rng):
-    kind = str(rng.choice(["amf", "amf_levels", "MOPITT", "GOSAT"]))
+    kind = str(rng.choice(["amf", "amf_levels", "MOPITT", "GOSAT", "lattice", "noisy_lattice"]))
     seed = int(rng.integers(1, 10 ** 6))
     lat0 = float(rng.uniform(-40, 10))
     lat1 = lat0 + float(rng.uniform(8, 30))
@@ -133,6 +133,17 @@ def fuzz_interpolator(rng):
     if kind == "amf":
         g = syn.swath_granule(seed, nscan=nscan, npix=npix, lat0=lat0, lat1=lat1, lon_c=lon_c, width_deg=width)
         rec = cfg.satellite_amf
+    elif kind in ("lattice", "noisy_lattice"):       # a level-3 record; with 1e-13 deg of noise qhull closes the hull with slivers
+        step = float(rng.choice([0.5, 1.0]))
+        lat0, lat1 = np.floor(lat0) + 0.5, np.floor(lat0) + 0.5 + step * int(rng.integers(8, 24))
+        lon0 = np.floor(lon_c) + 0.5
+        lon1 = lon0 + step * int(rng.integers(8, 24))
+        g = syn.lattice_l3_granule(seed, sensor=str(rng.choice(["MOPITT", "GOSAT"])), nz=int(rng.integers(2, 4)), lat0=lat0, lat1=lat1, lon0=lon0, lon1=lon1, step=step)
+        rec = cfg.satellite_opt
+        if kind == "noisy_lattice":
+            g.latitude_center = g.latitude_center.astype(np.float64) + 1e-13 * rng.normal(size=g.latitude_center.shape)
+            g.longitude_center = g.longitude_center.astype(np.float64)
+        lon_c, width = 0.5 * (lon0 + lon1), lon1 - lon0
     else:
         g = syn.swath_level_granule(seed, kind="amf" if kind == "amf_levels" else kind, nz=int(rng.integers(2, 5)), nscan=nscan, npix=npix, lat0=lat0,
                                     lat1=lat1, lon_c=lon_c, width_deg=width)
@@ -140,7 +151,7 @@ def fuzz_interpolator(rng):
     gs = float(rng.choice([0.25, 0.5, 1.0]))
     dlat = gs * float(rng.choice([0.5, 1.0, 2.0, 4.0]))
     dlon = gs * float(rng.choice([0.5, 1.0, 2.5, 5.0]))
-    pad = float(rng.uniform(-3, 3))
+    pad = float(rng.uniform(-3, 3)) if "lattice" not in kind else float(rng.uniform(-3, -0.5))    # beyond a lattice's edge type 3 is singular
     ctm = syn.regional_ctm_grid(np.floor(lat0 - pad), np.ceil(lat1 + pad), np.floor(lon_c - width / 2 - pad), np.ceil(lon_c + width / 2 + pad), dlat, dlon)
     if min(ctm["Latitude"].shape) < 2:
         return
